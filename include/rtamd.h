@@ -1,0 +1,205 @@
+/*
+ * rtamd.h — C-ABI of the MI355X-native path-tracing render path.
+ *
+ * This is the drop-in boundary for the reference renderer's per-pixel render loop
+ * (reference: hw8/src/sceneio.cpp:381-402 `sceneio::renderScene`, whose parallel-for body
+ * calls `Scene::getPixel`, hw8/src/scene.cpp:167-177, then the tonemap chain
+ * hw8/src/color.cpp:4-31).  The reference has no FFI of its own; the functions below are
+ * what a binding for that seam needs (see INTEGRATION.md for the reference-side stub):
+ *
+ *   rt_scene_create   replaces  Scene::initBVH + Scene::initDistribution  (hw8/src/scene.cpp:65-78)
+ *                     plus the upload of the flattened scene to HBM (once).
+ *   rt_render         replaces  the `#pragma omp parallel for` of renderScene
+ *                     (hw8/src/sceneio.cpp:387-396): per-pixel minstd_rand(y*W+x) replay,
+ *                     getPixel, aces_tonemap/gamma_corrected/toExternColorFormat.
+ *   rt_scene_destroy  replaces  Scene::~Scene (hw8/src/scene.cpp:56-63).
+ *
+ * Conventions: plain C, plain pointers and sizes, no exceptions cross the boundary.
+ * Every function returns 0 on success and a negative rt_status on failure;
+ * rt_last_error() returns a thread-local message for the last failure.  The library owns all
+ * device memory; the caller owns every host buffer passed in and may free the rt_scene_desc
+ * arrays as soon as rt_scene_create returns.  One rt_scene lives on one GPU (the HIP device
+ * current at creation); calls on one rt_scene must be serialised by the caller.
+ * There is no CPU fallback: if no HIP device is usable the calls fail with RT_ERR_NO_DEVICE.
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTAMD_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1,
+    RT_ERR_NO_DEVICE = -2,
+    RT_ERR_HIP = -3,
+    RT_ERR_UNSUPPORTED = -4,
+    RT_ERR_IO = -5,
+    RT_ERR_PARSE = -6,
+    RT_ERR_LIMIT = -7
+} rt_status;
+
+/* Which reference integrator the render loop replays. */
+typedef enum rt_integrator {
+    RT_INTEGRATOR_HW1 = 1, /* ray caster,  hw1/src/scene.cpp:7-30   */
+    RT_INTEGRATOR_HW3 = 3, /* first path tracer over analytic primitives, hw3/src/scene.cpp:31-107 */
+    RT_INTEGRATOR_HW6 = 6, /* triangles, DIFFUSE/METALLIC/DIELECTRIC, hw6/src/scene.cpp:47-105    */
+    RT_INTEGRATOR_HW8 = 8  /* glTF PBR + textures + mixture sampling, hw8/src/scene.cpp:84-165     */
+} rt_integrator;
+
+/* hw3/hw6 material classes (hw3/src/include/primitives.h, hw6/src/include/primitives.h). */
+typedef enum rt_material_kind { RT_MAT_DIFFUSE = 0, RT_MAT_METALLIC = 1, RT_MAT_DIELECTRIC = 2 } rt_material_kind;
+
+/* glTF material as the reference keeps it (hw8/src/include/gltf_structs.h:38-47).
+ * Texture fields are glTF *texture* indices (into rt_scene_desc.texture_source) or -1. */
+typedef struct rt_material {
+    float base_color[3];   /* baseColorFactor rgb, default 1,1,1 */
+    float emission[3];     /* emissiveFactor * KHR_materials_emissive_strength, default 0 */
+    float metallic_factor; /* default 1 */
+    float roughness_factor;/* default 1 */
+    int32_t base_color_texture;
+    int32_t emissive_texture;
+    int32_t metallic_roughness_texture;
+    int32_t normal_texture;
+    int32_t kind;          /* rt_material_kind; used by the HW3/HW6 integrators only */
+    float ior;             /* HW3/HW6 dielectric index of refraction */
+} rt_material;
+
+/* 8-bit RGB image, row 0 first, tightly packed (what stbi_load(...,3) hands the reference,
+ * hw8/src/sceneio.cpp:374-379). */
+typedef struct rt_image {
+    int32_t width, height;
+    const uint8_t *rgb;
+} rt_image;
+
+/* Analytic primitive of the .txt scenes (hw1/hw3: hw3/src/include/primitives.h:17-44). */
+typedef enum rt_primitive_type { RT_PRIM_ELLIPSOID = 0, RT_PRIM_PLANE = 1, RT_PRIM_BOX = 2 } rt_primitive_type;
+typedef struct rt_primitive {
+    int32_t type;        /* rt_primitive_type */
+    float data[3];       /* radii | plane normal | box half-sizes */
+    float position[3];
+    float rotation[4];   /* quaternion x,y,z,w exactly as parsed (may be non-unit) */
+    float color[3];
+    float emission[3];
+    int32_t kind;        /* rt_material_kind */
+    float ior;
+} rt_primitive;
+
+typedef struct rt_camera {
+    float position[3], right[3], up[3], forward[3];
+    float fov_y;         /* glTF scenes (hw6-hw8): yfov in radians */
+    float fov_x;         /* .txt scenes (hw1-hw5): CAMERA_FOV_X in radians */
+} rt_camera;
+
+/* Scene description: host arrays in LOAD order (the order the reference's loader appends
+ * Figures, hw8/src/sceneio.cpp:247-310).  Per triangle the three vertices are stored in the
+ * order of the reference's Figure members (data, data2, data3) — i.e. glTF corners (1,3,2),
+ * hw8/src/sceneio.cpp:289. */
+typedef struct rt_scene_desc {
+    uint32_t struct_size;            /* = sizeof(rt_scene_desc) */
+    uint32_t n_triangles;
+    const float *positions;          /* n_triangles * 9  */
+    const float *texcoords;          /* n_triangles * 6  (may be NULL for HW6) */
+    const float *normals;            /* n_triangles * 9  (may be NULL for HW6) */
+    const float *tangents;           /* n_triangles * 12 (xyz,w; may be NULL for HW6) */
+    const uint32_t *material_index;  /* n_triangles */
+    uint32_t n_materials;
+    const rt_material *materials;
+    uint32_t n_textures;
+    const uint32_t *texture_source;  /* glTF textures[i].source */
+    uint32_t n_images;
+    const rt_image *images;
+    const rt_image *environment_map; /* NULL = none (hw8/src/scene.cpp:90-97) */
+    uint32_t n_primitives;           /* analytic primitives (HW1/HW3) */
+    const rt_primitive *primitives;
+    rt_camera camera;
+    float bg_color[3];
+} rt_scene_desc;
+
+#define RT_FLAG_OUT_DEVICE 1u /* out_rgb_linear / out_rgb8 are device pointers on the scene's GPU */
+#define RT_FLAG_COUNTERS   2u /* also fill the work counters of rt_stats (slower kernel variant) */
+
+typedef struct rt_render_params {
+    uint32_t struct_size; /* = sizeof(rt_render_params) */
+    int32_t width, height, samples;
+    int32_t ray_depth;    /* 0 = reference default (6, hw8/src/include/scene.h:32) */
+    int32_t integrator;   /* rt_integrator */
+    /* Sharding for multi-GPU: the image is cut into tile_w x tile_h tiles numbered row-major;
+     * tile t belongs to shard (t % shard_count).  shard_count <= 1 renders the whole image
+     * into a plain W*H*3 row-major buffer; otherwise the output is the compact sequence of
+     * this shard's tiles (each tile_h*tile_w*3, border tiles zero-padded). */
+    int32_t tile_w, tile_h;
+    int32_t shard_index, shard_count;
+    uint32_t flags;
+    void *stream;         /* hipStream_t to launch on, NULL = default stream */
+} rt_render_params;
+
+typedef struct rt_stats {
+    double kernel_ms;       /* HIP-event time of the render kernel(s) on the launch stream */
+    double total_ms;        /* host wall time of rt_render */
+    uint64_t samples;       /* camera samples rendered by this call */
+    uint64_t closest_hit_queries, light_pdf_queries; /* RT_FLAG_COUNTERS */
+    uint64_t node_visits, triangle_tests;            /* RT_FLAG_COUNTERS */
+    uint32_t launches;
+    uint32_t reserved;
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+int rt_abi_version(void);
+const char *rt_last_error(void);
+
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+
+/* Number of floats (or bytes for rgb8) rt_render writes for these params. */
+size_t rt_output_elems(const rt_render_params *params);
+
+int rt_render(rt_scene *scene, const rt_render_params *params,
+              float *out_rgb_linear /* nullable */, uint8_t *out_rgb8 /* nullable */,
+              rt_stats *stats /* nullable */);
+
+/* Scatter a compact shard buffer (layout above) into a full W*H*3 host image. */
+int rt_unshard(const rt_render_params *params, const void *shard_buf, size_t elem_size,
+               void *full_image);
+
+/* Scene info the host side needs after preparation. */
+typedef struct rt_scene_info {
+    uint32_t n_triangles, n_lights, n_bvh_nodes, n_light_bvh_nodes;
+    uint32_t bvh_depth, light_bvh_depth;
+    uint64_t device_bytes;
+    double prep_ms, upload_ms;
+} rt_scene_info;
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);
+/* Light order chosen by preparation (indices into the LOAD-order triangle arrays);
+ * parity-critical: reference hw8/src/include/distributions.h:103-115. */
+int rt_scene_get_light_order(const rt_scene *scene, uint32_t *out, uint32_t capacity);
+
+/* ---- host-side front-end (replaces sceneio::loadScene / loadTexture) -------------------- */
+typedef struct rt_host_scene rt_host_scene; /* owns the arrays a desc points into */
+
+/* glTF 2.0 subset loader, float-for-float the reference's (hw8/src/sceneio.cpp:348-372).
+ * flavor: RT_INTEGRATOR_HW6 or RT_INTEGRATOR_HW8 (material interpretation differs). */
+int rt_load_gltf(const char *path, int flavor, rt_host_scene **out);
+/* .txt scene loader (hw1/hw3 grammar, hw3/src/sceneio.cpp:62-107). Fills width/height/samples/ray_depth. */
+int rt_load_txt(const char *path, int flavor, rt_host_scene **out,
+                int32_t *width, int32_t *height, int32_t *samples, int32_t *ray_depth);
+int rt_host_scene_set_environment(rt_host_scene *hs, const char *image_path);
+const rt_scene_desc *rt_host_scene_desc(const rt_host_scene *hs);
+void rt_host_scene_free(rt_host_scene *hs);
+/* Binary PPM writer (hw8/src/sceneio.cpp:383-385,397-401). */
+int rt_write_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb8);
+/* PNG (8-bit gray/RGB/RGBA/palette, non-interlaced) decode to 3-channel RGB; caller frees with rt_free. */
+int rt_decode_png(const char *path, int32_t *width, int32_t *height, uint8_t **rgb);
+void rt_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

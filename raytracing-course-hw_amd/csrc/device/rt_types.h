@@ -1,0 +1,99 @@
+// Flat HBM layouts shared by the host preparation (scene_prep.cpp) and the HIP kernels.
+// Everything is plain old data, 16-byte aligned records so one lane fetches a record with
+// global_load_dwordx4 instructions.
+#pragma once
+#include <stdint.h>
+
+namespace rtamd {
+
+// Binary BVH node with BOTH child boxes inline (one 64-byte fetch decides both children).
+// child = index of an inner node, or 0x80000000|first for a leaf whose primitives run from `first`
+// up to the record whose `pad` word is 1 (cnt repeats the count for diagnostics), or 0xFFFFFFFF (empty).
+// Boxes are padded conservatively on the host (see scene_prep.cpp pad_box).
+struct GpuNode {
+    float lo0[3]; int32_t child0;
+    float hi0[3]; int32_t cnt0;
+    float lo1[3]; int32_t child1;
+    float hi1[3]; int32_t cnt1;
+};
+static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 bytes");
+
+// Per-triangle intersection record, in the reference's BVH (figure) order.  All derived values are
+// computed on the host with the reference's float expressions (hw8/src/primitives.cpp:85-104), so
+// the kernel's test is bit-identical to Figure::intersectAsTriangle while fetching only 48 bytes.
+struct TriIsect {
+    float ax, ay, az;   // a = data3.coords
+    float nx, ny, nz;   // n = b.cross(c) (negated cross convention), b = data - a, c = data2 - a
+    float a1, b1;       // magic1 . b, magic1 . c
+    float a2, b2;       // magic2 . b, magic2 . c
+    float den;          // b1*a2 - a1*b2
+    uint32_t pad;
+};
+static_assert(sizeof(TriIsect) == 48, "TriIsect must be 48 bytes");
+
+// Per-triangle shading record (fetched once per hit): interpolation bases and deltas
+// (hw8/src/primitives.cpp:110-117) plus material.
+struct TriShade {
+    float n3[3], dn1[3], dn2[3];   // data3.normals, data.normals-data3.normals, data2.normals-data3.normals
+    float t3[3], dt1[3], dt2[3];   // same for tangents.v
+    float uv3[2], duv1[2], duv2[2];
+    float tanw;                    // data.tangents.w
+    uint32_t material;
+    uint32_t orig;                 // LOAD-order index (diagnostics)
+    uint32_t pad;
+};
+static_assert(sizeof(TriShade) == 112, "TriShade must be 112 bytes");
+
+// Emissive triangle in the reference's light order (hw8/src/include/distributions.h:60-115).
+struct LightRec {
+    TriIsect isect;                // for pdfOneFigureLight's intersection test
+    float b[3], c[3];              // for TriangleLight::sample: point = a + u*b + v*c
+    float point_prob;              // 1 / area
+    float n3[3], dn1[3], dn2[3];   // shading-normal interpolation (pdfOne uses the shading normal in hw8)
+};
+static_assert(sizeof(LightRec) == 48 + 64, "LightRec must be 112 bytes");
+
+struct GpuMaterial {
+    float base_color[3]; float metallic_factor;
+    float emission[3];   float roughness_factor;
+    int32_t base_color_tex, emissive_tex, metallic_roughness_tex, normal_tex; // image slot or -1
+};
+static_assert(sizeof(GpuMaterial) == 48, "GpuMaterial must be 48 bytes");
+
+struct GpuImage {
+    uint64_t offset; // byte offset of the RGB8 data in the texel buffer
+    int32_t width, height;
+};
+
+// Device-side view of a prepared scene (pointers into HBM).
+struct SceneView {
+    const GpuNode *nodes;          // scene BVH, root = 0
+    const TriIsect *tri_isect;
+    const TriShade *tri_shade;
+    const GpuNode *light_nodes;    // light BVH in the reference's topology, root = 0
+    const LightRec *lights;
+    const GpuMaterial *materials;
+    const GpuImage *images;
+    const uint8_t *texels;
+    const float *srgb_lut;         // 256 entries: powf(float(1/255.)*b, 2.2f) evaluated by the host libm
+    uint32_t n_tris, n_lights, n_components;
+    int32_t env_image;             // image slot of the environment map or -1
+    float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
+    float bg[3];
+    float tan_fov_y;               // (float)tan((double)(fovY / 2)), hw8/src/scene.cpp:180
+};
+
+struct RenderView {
+    int32_t width, height, samples, ray_depth;
+    int32_t tile_w, tile_h, tiles_x, tiles_y;
+    int32_t shard_index, shard_count;
+    uint32_t n_shard_tiles;
+    float tan_fov_x;               // tanFovY * width / height, hw8/src/scene.cpp:181
+    float inv_samples;             // (float)(1.0 / samples), hw8/src/scene.cpp:176
+    float *out_rgb;                // nullable
+    uint8_t *out_rgb8;             // nullable
+    uint32_t *work_counter;        // dynamic tile queue head
+    unsigned long long *counters;  // nullable: [closest, lightq, node_visits, tri_tests]
+};
+
+} // namespace rtamd

@@ -1,0 +1,322 @@
+// Host-side scene preparation: everything Scene::initBVH + Scene::initDistribution do in the
+// reference (hw8/src/scene.cpp:65-78), re-expressed for the GPU:
+//
+//  1. figure order   — the reference's BVH build physically reorders `figures` with std::sort on the
+//                      data3 vertex (hw8/src/include/bvh.h:60-109).  That order is part of the
+//                      semantics (ties in t keep the lowest index; the light list is cut from it), so
+//                      it is reproduced here by running the same libstdc++ algorithms with the same
+//                      comparators on (key, index) pairs.
+//  2. light order    — std::partition(emissive first) of a copy, then the same build over the first
+//                      n (hw8/src/include/distributions.h:103-115).
+//  3. GPU layouts    — the two trees are re-encoded as 64-byte two-box nodes over records stored in
+//                      that order (rt_types.h); boxes are padded so the kernel's fast slab test is
+//                      conservative, triangle records carry host-evaluated reference sub-expressions.
+//
+// Build with -ffp-contract=off (reference float semantics for the precomputed sub-expressions).
+#include "scene_prep.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+namespace rtamd {
+namespace {
+
+inline float smin(float a, float b) { return (b < a) ? b : a; } // std::min
+inline float smax(float a, float b) { return (a < b) ? b : a; } // std::max
+
+struct Box3 { float lo[3], hi[3]; };
+
+inline float surface(const Box3 &b) { // primitives.cpp:158-161
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return 2 * (dx * dy + dx * dz + dy * dz);
+}
+inline void grow(Box3 &b, const Box3 &o) {
+    for (int k = 0; k < 3; k++) { b.lo[k] = smin(b.lo[k], o.lo[k]); b.hi[k] = smax(b.hi[k], o.hi[k]); }
+}
+
+// Reference-topology builder over an index permutation.
+struct RefNode { Box3 box; uint32_t left = 0, right = 0, first = 0, last = 0; };
+
+class RefBuilder {
+public:
+    // keys[axis][tri] = data3 coordinate, boxes[tri] = triangle AABB; `order` is permuted in place.
+    RefBuilder(const std::vector<float> *keys, const std::vector<Box3> &boxes, std::vector<uint32_t> &order)
+        : keys_(keys), boxes_(boxes), order_(order), pairs_(order.size()), scores_(order.size()), suffix_(order.size()) {}
+
+    std::vector<RefNode> nodes;
+    uint32_t depth = 0;
+
+    void run(uint32_t n) { nodes.clear(); depth = 0; build(0, n, 1); }
+
+private:
+    struct KI { float k; uint32_t i; };
+    const std::vector<float> *keys_;
+    const std::vector<Box3> &boxes_;
+    std::vector<uint32_t> &order_;
+    std::vector<KI> pairs_;
+    std::vector<float> scores_;
+    std::vector<float> suffix_;
+
+    void sort_axis(uint32_t first, uint32_t last, int axis) { // bvh.h:60-65
+        const std::vector<float> &key = keys_[axis];
+        for (uint32_t i = first; i < last; i++) pairs_[i] = KI{key[order_[i]], order_[i]};
+        std::sort(pairs_.begin() + first, pairs_.begin() + last, [](const KI &l, const KI &r) { return l.k < r.k; });
+        for (uint32_t i = first; i < last; i++) order_[i] = pairs_[i].i;
+    }
+    std::pair<float, uint32_t> best_split(uint32_t first, uint32_t last) { // bvh.h:34-54
+        uint32_t n = last - first;
+        float *sc = scores_.data() + first;
+        sc[0] = 0;
+        Box3 pre = boxes_[order_[first]];
+        for (size_t i = 1; i < n; i++) {
+            sc[i] = surface(pre) * i;
+            grow(pre, boxes_[order_[first + i]]);
+        }
+        Box3 suf = boxes_[order_[last - 1]];
+        for (size_t i = n - 1; i >= 1; i--) {
+            sc[i] += surface(suf) * (n - i);
+            grow(suf, boxes_[order_[first + i - 1]]);
+        }
+        std::pair<float, uint32_t> ans = {sc[1], first + 1};
+        for (size_t i = 2; i < n; i++)
+            if (sc[i] < ans.first) ans = {sc[i], (uint32_t)(first + i)};
+        return ans;
+    }
+    uint32_t build(uint32_t first, uint32_t last, uint32_t d) { // bvh.h:67-109
+        if (d > depth) depth = d;
+        RefNode cur;
+        cur.first = first; cur.last = last;
+        if (first < last) {
+            cur.box = boxes_[order_[first]];
+            for (uint32_t i = first + 1; i < last; i++) grow(cur.box, boxes_[order_[i]]);
+        } else memset(&cur.box, 0, sizeof cur.box);
+        uint32_t pos = (uint32_t)nodes.size();
+        nodes.push_back(cur);
+        if (last - first <= 1) return pos;
+        sort_axis(first, last, 0); auto sx = best_split(first, last);
+        sort_axis(first, last, 1); auto sy = best_split(first, last);
+        sort_axis(first, last, 2); auto sz = best_split(first, last);
+        float best = smin(sx.first, smin(sy.first, sz.first));
+        if (best >= surface(cur.box) * (last - first)) return pos; // leaf with >1 triangles, z-sorted
+        uint32_t mid;
+        if (best == sx.first) { mid = sx.second; sort_axis(first, last, 0); }
+        else if (best == sy.first) { mid = sy.second; sort_axis(first, last, 1); }
+        else { mid = sz.second; sort_axis(first, last, 2); }
+        uint32_t l = build(first, mid, d + 1);
+        nodes[pos].left = l;
+        uint32_t r = build(mid, last, d + 1);
+        nodes[pos].right = r;
+        return pos;
+    }
+};
+
+// Conservative padding for the kernel's reciprocal-multiply slab test: 2^-17 relative to the
+// coordinate magnitude (64 ulp) on every face.
+inline void pad_box(const Box3 &b, float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; k++) {
+        float mag = smax(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+        float pad = mag * 7.62939453125e-06f + 1e-30f;
+        lo[k] = b.lo[k] - pad;
+        hi[k] = b.hi[k] + pad;
+    }
+}
+
+// Re-encode a reference tree as two-box GpuNodes (child reference: inner node index, or
+// 0x80000000|first for a leaf, 0xFFFFFFFF for an empty leaf).  `leaf_last` receives the index of
+// the last primitive of every leaf; the kernels walk a leaf until they meet that mark.
+void encode_tree(const std::vector<RefNode> &ref, std::vector<GpuNode> &out, std::vector<uint32_t> &leaf_last) {
+    out.clear();
+    leaf_last.clear();
+    auto empty_child = [](float lo[3], float hi[3], int32_t &child, int32_t &cnt) {
+        for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = 3.0e38f; }
+        child = (int32_t)0xFFFFFFFFu; cnt = 0;
+    };
+    auto leaf_ref = [&](const RefNode &l, int32_t &child, int32_t &cnt) {
+        child = (int32_t)(0x80000000u | l.first); cnt = (int32_t)(l.last - l.first);
+        leaf_last.push_back(l.last - 1);
+    };
+    if (ref.empty() || ref[0].last == ref[0].first) { // no primitives: one node, two empty leaves
+        GpuNode g;
+        empty_child(g.lo0, g.hi0, g.child0, g.cnt0);
+        empty_child(g.lo1, g.hi1, g.child1, g.cnt1);
+        out.push_back(g);
+        return;
+    }
+    if (ref[0].left == 0) { // root is a leaf: wrap it
+        GpuNode g;
+        pad_box(ref[0].box, g.lo0, g.hi0);
+        leaf_ref(ref[0], g.child0, g.cnt0);
+        empty_child(g.lo1, g.hi1, g.child1, g.cnt1);
+        out.push_back(g);
+        return;
+    }
+    // Inner reference nodes get GPU indices in DFS preorder (root = 0).
+    std::vector<int32_t> gpu_index(ref.size(), -1);
+    int32_t next = 0;
+    for (size_t i = 0; i < ref.size(); i++)
+        if (ref[i].left != 0) gpu_index[i] = next++;
+    out.resize(next);
+    for (size_t i = 0; i < ref.size(); i++) {
+        if (ref[i].left == 0) continue;
+        GpuNode &g = out[gpu_index[i]];
+        const RefNode &l = ref[ref[i].left], &r = ref[ref[i].right];
+        pad_box(l.box, g.lo0, g.hi0);
+        pad_box(r.box, g.lo1, g.hi1);
+        if (l.left == 0) leaf_ref(l, g.child0, g.cnt0);
+        else { g.child0 = gpu_index[ref[i].left]; g.cnt0 = 0; }
+        if (r.left == 0) leaf_ref(r, g.child1, g.cnt1);
+        else { g.child1 = gpu_index[ref[i].right]; g.cnt1 = 0; }
+    }
+}
+
+struct V3 { float x, y, z; };
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 crossr(V3 a, V3 o) { return {a.z * o.y - a.y * o.z, a.x * o.z - a.z * o.x, a.y * o.x - a.x * o.y}; } // vec3.h:57-59
+
+const float magic1[] = {0.239, 0.419, 0.533};       // primitives.cpp:82
+const float magic2[] = {0.35743, 0.66682, 0.69695}; // primitives.cpp:83
+
+TriIsect make_isect(const float *p /* data, data2, data3 */) {
+    V3 d0{p[0], p[1], p[2]}, d1{p[3], p[4], p[5]}, a{p[6], p[7], p[8]};
+    V3 b = sub(d0, a), c = sub(d1, a);
+    V3 n = crossr(b, c);
+    TriIsect t;
+    t.ax = a.x; t.ay = a.y; t.az = a.z;
+    t.nx = n.x; t.ny = n.y; t.nz = n.z;
+    t.a1 = magic1[0] * b.x + magic1[1] * b.y + magic1[2] * b.z;
+    t.b1 = magic1[0] * c.x + magic1[1] * c.y + magic1[2] * c.z;
+    t.a2 = magic2[0] * b.x + magic2[1] * b.y + magic2[2] * b.z;
+    t.b2 = magic2[0] * c.x + magic2[1] * c.y + magic2[2] * c.z;
+    t.den = t.b1 * t.a2 - t.a1 * t.b2;
+    t.pad = 0;
+    return t;
+}
+
+} // namespace
+
+void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
+    const uint32_t n = d.n_triangles;
+    if (n >= 0x7FFFFFFFu) throw std::runtime_error("too many triangles (limit 2^31-2)");
+    if (n && (!d.positions || !d.material_index)) throw std::runtime_error("scene has triangles but no positions/material_index");
+    for (uint32_t i = 0; i < n; i++)
+        if (d.material_index[i] >= d.n_materials) throw std::runtime_error("triangle material index out of range");
+
+    // ---- 1. figure order (scene BVH) --------------------------------------------------------------
+    std::vector<float> keys[3];
+    std::vector<Box3> boxes(n);
+    for (int k = 0; k < 3; k++) keys[k].resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *p = d.positions + 9 * (size_t)i;
+        for (int k = 0; k < 3; k++) {
+            keys[k][i] = p[6 + k]; // data3
+            boxes[i].lo[k] = smin(p[6 + k], smin(p[k], p[3 + k])); // primitives.cpp:130-141
+            boxes[i].hi[k] = smax(p[6 + k], smax(p[k], p[3 + k]));
+        }
+    }
+    out.figure_order.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.figure_order[i] = i;
+    RefBuilder scene_builder(keys, boxes, out.figure_order);
+    scene_builder.run(n);
+    out.bvh_depth = scene_builder.depth;
+    out.ref_nodes = (uint32_t)scene_builder.nodes.size();
+    std::vector<uint32_t> scene_leaf_last, light_leaf_last;
+    encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
+
+    // ---- 2. light order ---------------------------------------------------------------------------
+    auto emissive = [&](uint32_t tri) { // distributions.h:104-109: the FACTOR decides, not the texture
+        const rt_material &m = d.materials[d.material_index[tri]];
+        return !(m.emission[0] == 0 && m.emission[1] == 0 && m.emission[2] == 0);
+    };
+    std::vector<uint32_t> lorder = out.figure_order; // the copy FiguresMix receives by value
+    uint32_t n_lights = (uint32_t)(std::partition(lorder.begin(), lorder.end(), emissive) - lorder.begin());
+    RefBuilder light_builder(keys, boxes, lorder);
+    light_builder.run(n_lights);
+    out.light_bvh_depth = light_builder.depth;
+    encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
+
+    // ---- 3. records ---------------------------------------------------------------------------------
+    out.isect.resize(n);
+    out.shade.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t src = out.figure_order[i];
+        out.isect[i] = make_isect(d.positions + 9 * (size_t)src);
+        TriShade &s = out.shade[i];
+        memset(&s, 0, sizeof s);
+        if (d.normals) {
+            const float *q = d.normals + 9 * (size_t)src;
+            for (int k = 0; k < 3; k++) { s.n3[k] = q[6 + k]; s.dn1[k] = q[k] - q[6 + k]; s.dn2[k] = q[3 + k] - q[6 + k]; }
+        }
+        if (d.tangents) {
+            const float *q = d.tangents + 12 * (size_t)src;
+            for (int k = 0; k < 3; k++) { s.t3[k] = q[8 + k]; s.dt1[k] = q[k] - q[8 + k]; s.dt2[k] = q[4 + k] - q[8 + k]; }
+            s.tanw = q[3];
+        }
+        if (d.texcoords) {
+            const float *q = d.texcoords + 6 * (size_t)src;
+            for (int k = 0; k < 2; k++) { s.uv3[k] = q[4 + k]; s.duv1[k] = q[k] - q[4 + k]; s.duv2[k] = q[2 + k] - q[4 + k]; }
+        }
+        s.material = d.material_index[src];
+        s.orig = src;
+    }
+    for (uint32_t i : scene_leaf_last) out.isect[i].pad = 1;
+    out.lights.resize(n_lights);
+    for (uint32_t i = 0; i < n_lights; i++) {
+        uint32_t src = out.light_order[i];
+        const float *p = d.positions + 9 * (size_t)src;
+        LightRec &L = out.lights[i];
+        memset(&L, 0, sizeof L);
+        L.isect = make_isect(p);
+        for (int k = 0; k < 3; k++) { L.b[k] = p[k] - p[6 + k]; L.c[k] = p[3 + k] - p[6 + k]; }
+        float nl2 = L.isect.nx * L.isect.nx + L.isect.ny * L.isect.ny + L.isect.nz * L.isect.nz;
+        float nl = (float)std::sqrt((double)nl2);
+        L.point_prob = (float)(1.0 / (0.5 * (double)nl)); // distributions.h:78
+        if (d.normals) {
+            const float *q = d.normals + 9 * (size_t)src;
+            for (int k = 0; k < 3; k++) { L.n3[k] = q[6 + k]; L.dn1[k] = q[k] - q[6 + k]; L.dn2[k] = q[3 + k] - q[6 + k]; }
+        }
+    }
+
+    for (uint32_t i : light_leaf_last) out.lights[i].isect.pad = 1;
+
+    // ---- materials, images ------------------------------------------------------------------------
+    out.images.clear();
+    out.texels.clear();
+    auto add_image = [&](const rt_image &im) -> int32_t {
+        if (im.width <= 0 || im.height <= 0 || !im.rgb) throw std::runtime_error("image with no pixels");
+        GpuImage g;
+        g.offset = out.texels.size();
+        g.width = im.width; g.height = im.height;
+        size_t bytes = (size_t)im.width * im.height * 3;
+        out.texels.insert(out.texels.end(), im.rgb, im.rgb + bytes);
+        while (out.texels.size() % 16) out.texels.push_back(0);
+        out.images.push_back(g);
+        return (int32_t)out.images.size() - 1;
+    };
+    for (uint32_t i = 0; i < d.n_images; i++) add_image(d.images[i]);
+    out.env_image = d.environment_map ? add_image(*d.environment_map) : -1;
+    auto slot = [&](int32_t tex) -> int32_t {
+        if (tex < 0) return -1;
+        if ((uint32_t)tex >= d.n_textures) throw std::runtime_error("material texture index out of range");
+        uint32_t src = d.texture_source[tex];
+        if (src >= d.n_images) throw std::runtime_error("texture source out of range");
+        return (int32_t)src;
+    };
+    out.materials.resize(d.n_materials);
+    for (uint32_t i = 0; i < d.n_materials; i++) {
+        const rt_material &m = d.materials[i];
+        GpuMaterial &g = out.materials[i];
+        for (int k = 0; k < 3; k++) { g.base_color[k] = m.base_color[k]; g.emission[k] = m.emission[k]; }
+        g.metallic_factor = m.metallic_factor; g.roughness_factor = m.roughness_factor;
+        g.base_color_tex = slot(m.base_color_texture); g.emissive_tex = slot(m.emissive_texture);
+        g.metallic_roughness_tex = slot(m.metallic_roughness_texture); g.normal_tex = slot(m.normal_texture);
+    }
+    // sRGB decode table: loadSingleFromTexture (scene.cpp:9-16) applies std::pow(float, 2.2f) to
+    // float(1./255)*byte; only 256 inputs exist, so the host libm (the one the reference itself
+    // would call) evaluates them once and the kernel looks them up: bit-exact and cheaper.
+    for (int b = 0; b < 256; b++) out.srgb_lut[b] = std::pow((float)(1. / 255) * (1.f * (float)b), 2.2f);
+}
+
+} // namespace rtamd

@@ -1,0 +1,363 @@
+// C-ABI of the render path (include/rtamd.h): scene upload, render launch, output handling.
+// No CPU fallback exists: every entry point that needs the GPU fails with RT_ERR_NO_DEVICE / RT_ERR_HIP
+// when HIP is unusable.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/rtamd.h"
+#include "host/host_scene.h"
+#include "host/png.h"
+#include "host/scene_prep.h"
+#include "device/rt_kernels_hw8.h"
+
+namespace rtamd {
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+}
+using namespace rtamd;
+
+namespace {
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string &m) : std::runtime_error(m) {}
+};
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class T> T *upload(const std::vector<T> &v, uint64_t &bytes) {
+    if (v.empty()) { // keep pointers valid: one dummy element
+        void *p = nullptr;
+        HIP_CHECK(hipMalloc(&p, sizeof(T) > 16 ? sizeof(T) : 16));
+        HIP_CHECK(hipMemset(p, 0, sizeof(T) > 16 ? sizeof(T) : 16));
+        return (T *)p;
+    }
+    void *p = nullptr;
+    size_t n = v.size() * sizeof(T);
+    HIP_CHECK(hipMalloc(&p, n));
+    HIP_CHECK(hipMemcpy(p, v.data(), n, hipMemcpyHostToDevice));
+    bytes += n;
+    return (T *)p;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int fail(int code, const std::string &msg) {
+    set_error(msg);
+    return code;
+}
+
+} // namespace
+
+struct rt_scene {
+    int device = 0;
+    SceneView view{};
+    std::vector<void *> allocations;
+    rt_scene_info info{};
+    std::vector<uint32_t> light_order;
+    float fov_y = 0;
+    uint32_t *d_work_counter = nullptr;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int n_cus = 256;
+    ~rt_scene() {
+        for (void *p : allocations) (void)hipFree(p);
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_stop) (void)hipEventDestroy(ev_stop);
+    }
+};
+
+extern "C" {
+
+int rt_abi_version(void) { return RTAMD_ABI_VERSION; }
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
+    if (!desc || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
+    if (desc->struct_size != sizeof(rt_scene_desc)) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: struct_size mismatch (ABI skew)");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device available (this library has no CPU fallback)");
+    try {
+        std::unique_ptr<rt_scene> s(new rt_scene());
+        HIP_CHECK(hipGetDevice(&s->device));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, s->device));
+        s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        double t0 = now_ms();
+        PreparedScene P;
+        prepare_scene(*desc, P);
+        double t1 = now_ms();
+        if (P.bvh_depth > RT_STACK_SIZE - 2 || P.light_bvh_depth > RT_STACK_SIZE - 2)
+            return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P.bvh_depth) + "/" +
+                                          std::to_string(P.light_bvh_depth) + ")");
+        uint64_t bytes = 0;
+        SceneView &V = s->view;
+        auto keep = [&](auto *p) { s->allocations.push_back((void *)p); return p; };
+        V.nodes = keep(upload(P.nodes, bytes));
+        V.tri_isect = keep(upload(P.isect, bytes));
+        V.tri_shade = keep(upload(P.shade, bytes));
+        V.light_nodes = keep(upload(P.light_nodes, bytes));
+        V.lights = keep(upload(P.lights, bytes));
+        V.materials = keep(upload(P.materials, bytes));
+        V.images = keep(upload(P.images, bytes));
+        V.texels = keep(upload(P.texels, bytes));
+        std::vector<float> lut(P.srgb_lut, P.srgb_lut + 256);
+        V.srgb_lut = keep(upload(lut, bytes));
+        V.n_tris = desc->n_triangles;
+        V.n_lights = (uint32_t)P.lights.size();
+        V.n_components = P.lights.empty() ? 2u : 3u; // scene.cpp:65-74
+        V.env_image = P.env_image;
+        for (int k = 0; k < 3; k++) {
+            V.cam_pos[k] = desc->camera.position[k]; V.cam_right[k] = desc->camera.right[k];
+            V.cam_up[k] = desc->camera.up[k]; V.cam_fwd[k] = desc->camera.forward[k];
+            V.bg[k] = desc->bg_color[k];
+        }
+        s->fov_y = desc->camera.fov_y;
+        V.tan_fov_y = (float)std::tan((double)(desc->camera.fov_y / 2)); // scene.cpp:180 (host libm, like the reference)
+        HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
+        s->allocations.push_back(s->d_work_counter);
+        HIP_CHECK(hipMalloc((void **)&s->d_counters, 64));
+        s->allocations.push_back(s->d_counters);
+        HIP_CHECK(hipEventCreate(&s->ev_start));
+        HIP_CHECK(hipEventCreate(&s->ev_stop));
+        HIP_CHECK(hipDeviceSynchronize());
+        double t2 = now_ms();
+        s->light_order = P.light_order;
+        s->info.n_triangles = desc->n_triangles;
+        s->info.n_lights = V.n_lights;
+        s->info.n_bvh_nodes = (uint32_t)P.nodes.size();
+        s->info.n_light_bvh_nodes = (uint32_t)P.light_nodes.size();
+        s->info.bvh_depth = P.bvh_depth;
+        s->info.light_bvh_depth = P.light_bvh_depth;
+        s->info.device_bytes = bytes;
+        s->info.prep_ms = t1 - t0;
+        s->info.upload_ms = t2 - t1;
+        *out = s.release();
+        return RT_OK;
+    } catch (const HipError &e) {
+        return fail(RT_ERR_HIP, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARG, e.what());
+    }
+}
+
+void rt_scene_destroy(rt_scene *scene) { delete scene; }
+
+int rt_scene_get_info(const rt_scene *scene, rt_scene_info *info) {
+    if (!scene || !info) return fail(RT_ERR_INVALID_ARG, "rt_scene_get_info: null argument");
+    *info = scene->info;
+    return RT_OK;
+}
+
+int rt_scene_get_light_order(const rt_scene *scene, uint32_t *out, uint32_t capacity) {
+    if (!scene || (!out && capacity)) return fail(RT_ERR_INVALID_ARG, "rt_scene_get_light_order: null argument");
+    if (capacity < scene->light_order.size()) return fail(RT_ERR_INVALID_ARG, "rt_scene_get_light_order: buffer too small");
+    memcpy(out, scene->light_order.data(), scene->light_order.size() * sizeof(uint32_t));
+    return (int)scene->light_order.size();
+}
+
+static bool resolve_tiles(const rt_render_params *p, RenderView &R, std::string &err) {
+    if (p->width <= 0 || p->height <= 0 || p->samples <= 0) { err = "width, height and samples must be positive"; return false; }
+    if ((int64_t)p->width * p->height >= 2147483647LL) { err = "image too large for the per-pixel seed (y*W+x must stay below 2^31-1)"; return false; }
+    R.width = p->width; R.height = p->height; R.samples = p->samples;
+    R.ray_depth = p->ray_depth > 0 ? p->ray_depth : 6;
+    if (R.ray_depth > RT_MAX_DEPTH) { err = "ray_depth above RT_MAX_DEPTH (16)"; return false; }
+    R.shard_count = p->shard_count > 1 ? p->shard_count : 1;
+    R.shard_index = p->shard_count > 1 ? p->shard_index : 0;
+    if (R.shard_index < 0 || R.shard_index >= R.shard_count) { err = "shard_index out of range"; return false; }
+    if (R.shard_count > 1) {
+        R.tile_w = p->tile_w > 0 ? p->tile_w : 32;
+        R.tile_h = p->tile_h > 0 ? p->tile_h : 32;
+        if ((R.tile_w & 7) || (R.tile_h & 7)) { err = "tile_w and tile_h must be multiples of 8"; return false; }
+    } else {
+        R.tile_w = R.tile_h = 8;
+    }
+    R.tiles_x = (R.width + R.tile_w - 1) / R.tile_w;
+    R.tiles_y = (R.height + R.tile_h - 1) / R.tile_h;
+    uint32_t total = (uint32_t)R.tiles_x * (uint32_t)R.tiles_y;
+    R.n_shard_tiles = total > (uint32_t)R.shard_index ? (total - (uint32_t)R.shard_index + (uint32_t)R.shard_count - 1) / (uint32_t)R.shard_count : 0;
+    return true;
+}
+
+size_t rt_output_elems(const rt_render_params *p) {
+    if (!p) return 0;
+    RenderView R{};
+    std::string err;
+    if (!resolve_tiles(p, R, err)) return 0;
+    if (R.shard_count > 1) return (size_t)R.n_shard_tiles * R.tile_w * R.tile_h * 3;
+    return (size_t)R.width * R.height * 3;
+}
+
+int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
+    if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
+    if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
+    if (p->integrator != RT_INTEGRATOR_HW8) return fail(RT_ERR_UNSUPPORTED, "rt_render: only RT_INTEGRATOR_HW8 is implemented in this build");
+    RenderView R{};
+    std::string err;
+    if (!resolve_tiles(p, R, err)) return fail(RT_ERR_INVALID_ARG, "rt_render: " + err);
+    double t0 = now_ms();
+    float *d_rgb = nullptr;
+    uint8_t *d_rgb8 = nullptr;
+    bool own_rgb = false, own_rgb8 = false;
+    try {
+        HIP_CHECK(hipSetDevice(scene->device));
+        hipStream_t stream = (hipStream_t)p->stream;
+        const bool out_dev = (p->flags & RT_FLAG_OUT_DEVICE) != 0;
+        const bool count = (p->flags & RT_FLAG_COUNTERS) != 0;
+        size_t elems = rt_output_elems(p);
+        if (out_rgb) {
+            if (out_dev) d_rgb = out_rgb;
+            else { HIP_CHECK(hipMalloc((void **)&d_rgb, elems * sizeof(float))); own_rgb = true; }
+        }
+        if (out_rgb8) {
+            if (out_dev) d_rgb8 = out_rgb8;
+            else { HIP_CHECK(hipMalloc((void **)&d_rgb8, elems)); own_rgb8 = true; }
+        }
+        R.out_rgb = d_rgb; R.out_rgb8 = d_rgb8;
+        R.work_counter = scene->d_work_counter;
+        R.counters = count ? scene->d_counters : nullptr;
+        // scene.cpp:181,176 — evaluated on the host in float exactly like the reference
+        R.tan_fov_x = scene->view.tan_fov_y * R.width / R.height;
+        R.inv_samples = (float)(1.0 / R.samples);
+        uint32_t n_work = R.n_shard_tiles * (uint32_t)((R.tile_w >> 3) * (R.tile_h >> 3));
+        HIP_CHECK(hipMemsetAsync(scene->d_work_counter, 0, 4, stream));
+        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 32, stream));
+        uint32_t blocks = (uint32_t)scene->n_cus * 16u;
+        if (blocks > n_work) blocks = n_work;
+        HIP_CHECK(hipEventRecord(scene->ev_start, stream));
+        if (blocks) {
+            if (count) hipLaunchKernelGGL(dev::render_hw8_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
+            else hipLaunchKernelGGL(dev::render_hw8_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipEventRecord(scene->ev_stop, stream));
+        if (own_rgb) HIP_CHECK(hipMemcpyAsync(out_rgb, d_rgb, elems * sizeof(float), hipMemcpyDeviceToHost, stream));
+        if (own_rgb8) HIP_CHECK(hipMemcpyAsync(out_rgb8, d_rgb8, elems, hipMemcpyDeviceToHost, stream));
+        unsigned long long h_cnt[4] = {0, 0, 0, 0};
+        if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 32, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
+        if (own_rgb) { (void)hipFree(d_rgb); own_rgb = false; }
+        if (own_rgb8) { (void)hipFree(d_rgb8); own_rgb8 = false; }
+        if (stats) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, scene->ev_start, scene->ev_stop));
+            memset(stats, 0, sizeof *stats);
+            stats->kernel_ms = ms;
+            stats->total_ms = now_ms() - t0;
+            stats->launches = blocks ? 1 : 0;
+            // pixels of this shard that lie inside the image
+            uint64_t px = 0;
+            for (uint32_t st = 0; st < R.n_shard_tiles; st++) {
+                uint32_t gt = R.shard_count > 1 ? (uint32_t)R.shard_index + st * (uint32_t)R.shard_count : st;
+                int tx0 = (int)(gt % (uint32_t)R.tiles_x) * R.tile_w, ty0 = (int)(gt / (uint32_t)R.tiles_x) * R.tile_h;
+                int w = R.width - tx0 < R.tile_w ? R.width - tx0 : R.tile_w, h = R.height - ty0 < R.tile_h ? R.height - ty0 : R.tile_h;
+                px += (uint64_t)w * h;
+            }
+            stats->samples = px * (uint64_t)R.samples;
+            stats->closest_hit_queries = h_cnt[0]; stats->light_pdf_queries = h_cnt[1];
+            stats->node_visits = h_cnt[2]; stats->triangle_tests = h_cnt[3];
+        }
+        return RT_OK;
+    } catch (const HipError &e) {
+        if (own_rgb) (void)hipFree(d_rgb);
+        if (own_rgb8) (void)hipFree(d_rgb8);
+        return fail(RT_ERR_HIP, e.what());
+    }
+}
+
+int rt_unshard(const rt_render_params *p, const void *shard_buf, size_t elem_size, void *full_image) {
+    if (!p || !shard_buf || !full_image || (elem_size != 1 && elem_size != 4)) return fail(RT_ERR_INVALID_ARG, "rt_unshard: bad argument");
+    RenderView R{};
+    std::string err;
+    if (!resolve_tiles(p, R, err)) return fail(RT_ERR_INVALID_ARG, "rt_unshard: " + err);
+    const uint8_t *src = (const uint8_t *)shard_buf;
+    uint8_t *dst = (uint8_t *)full_image;
+    size_t px = 3 * elem_size;
+    if (R.shard_count <= 1) { memcpy(dst, src, (size_t)R.width * R.height * px); return RT_OK; }
+    for (uint32_t st = 0; st < R.n_shard_tiles; st++) {
+        uint32_t gt = (uint32_t)R.shard_index + st * (uint32_t)R.shard_count;
+        int tx0 = (int)(gt % (uint32_t)R.tiles_x) * R.tile_w, ty0 = (int)(gt / (uint32_t)R.tiles_x) * R.tile_h;
+        int w = R.width - tx0 < R.tile_w ? R.width - tx0 : R.tile_w, h = R.height - ty0 < R.tile_h ? R.height - ty0 : R.tile_h;
+        for (int ly = 0; ly < h; ly++)
+            memcpy(dst + ((size_t)(ty0 + ly) * R.width + tx0) * px, src + (((size_t)st * R.tile_h + ly) * R.tile_w) * px, (size_t)w * px);
+    }
+    return RT_OK;
+}
+
+// ---- host-side front-end ---------------------------------------------------------------------------
+int rt_load_gltf(const char *path, int flavor, rt_host_scene **out) {
+    if (!path || !out) return fail(RT_ERR_INVALID_ARG, "rt_load_gltf: null argument");
+    *out = nullptr;
+    try {
+        *out = load_gltf(path, flavor);
+        return RT_OK;
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_PARSE, std::string("rt_load_gltf(") + path + "): " + e.what());
+    }
+}
+int rt_load_txt(const char *path, int flavor, rt_host_scene **out, int32_t *w, int32_t *h, int32_t *samples, int32_t *depth) {
+    if (!path || !out) return fail(RT_ERR_INVALID_ARG, "rt_load_txt: null argument");
+    *out = nullptr;
+    try {
+        *out = load_txt(path, flavor, w, h, samples, depth);
+        return RT_OK;
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_PARSE, std::string("rt_load_txt(") + path + "): " + e.what());
+    }
+}
+int rt_host_scene_set_environment(rt_host_scene *hs, const char *image_path) {
+    if (!hs || !image_path) return fail(RT_ERR_INVALID_ARG, "rt_host_scene_set_environment: null argument");
+    try {
+        int w, h;
+        load_image_rgb8(image_path, w, h, hs->env_data);
+        hs->env = rt_image{w, h, nullptr};
+        hs->has_env = true;
+        hs->finalize();
+        return RT_OK;
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_IO, e.what());
+    }
+}
+const rt_scene_desc *rt_host_scene_desc(const rt_host_scene *hs) { return hs ? &hs->desc : nullptr; }
+void rt_host_scene_free(rt_host_scene *hs) { delete hs; }
+
+int rt_write_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb8) { // sceneio.cpp:383-385,397-401
+    if (!path || !rgb8 || width <= 0 || height <= 0) return fail(RT_ERR_INVALID_ARG, "rt_write_ppm: bad argument");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RT_ERR_IO, std::string("rt_write_ppm: cannot open ") + path);
+    fprintf(f, "P6\n%d %d\n255\n", width, height);
+    size_t n = (size_t)width * height * 3;
+    bool ok = fwrite(rgb8, 1, n, f) == n;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RT_OK : fail(RT_ERR_IO, std::string("rt_write_ppm: short write to ") + path);
+}
+int rt_decode_png(const char *path, int32_t *width, int32_t *height, uint8_t **rgb) {
+    if (!path || !width || !height || !rgb) return fail(RT_ERR_INVALID_ARG, "rt_decode_png: null argument");
+    try {
+        std::vector<uint8_t> px;
+        int w, h;
+        load_image_rgb8(path, w, h, px);
+        *rgb = (uint8_t *)malloc(px.size());
+        if (!*rgb) return fail(RT_ERR_IO, "rt_decode_png: out of memory");
+        memcpy(*rgb, px.data(), px.size());
+        *width = w; *height = h;
+        return RT_OK;
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_IO, e.what());
+    }
+}
+void rt_free(void *p) { free(p); }
+
+} // extern "C"

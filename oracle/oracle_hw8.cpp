@@ -678,5 +678,11 @@ void rto_rng_kat(uint32_t seed, int n_u, int n_n, float *out) {
     for (int i = 0; i < n_u; i++) out[i] = u01(rng);
     for (int i = 0; i < n_n; i++) out[n_u + i] = n01(rng);
 }
+// Same engine, normals drawn first, then uniforms.
+void rto_rng_kat_normals_first(uint32_t seed, int n_n, int n_u, float *out) {
+    rng_t rng(seed); U01 u01(0.0, 1.0); N01 n01(0.0, 1.0);
+    for (int i = 0; i < n_n; i++) out[i] = n01(rng);
+    for (int i = 0; i < n_u; i++) out[n_n + i] = u01(rng);
+}
 
 } // extern "C"

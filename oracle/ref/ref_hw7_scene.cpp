@@ -12,6 +12,7 @@
 namespace { Vec3 v3(const float *p) { return Vec3(p[0], p[1], p[2]); } }
 
 extern "C" {
+#pragma GCC visibility push(default)
 void *ref7_create(const rt_scene_desc *d) {
     Scene *s = new Scene();
     for (uint32_t i = 0; i < d->n_materials; i++) {
@@ -56,4 +57,5 @@ int ref7_render(void *p, int width, int height, int samples, int ray_depth, int 
     }
     return 0;
 }
+#pragma GCC visibility pop
 }

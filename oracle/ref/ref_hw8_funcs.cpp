@@ -24,6 +24,7 @@ Vec3 v3(const float *p) { return Vec3(p[0], p[1], p[2]); }
 }
 
 extern "C" {
+#pragma GCC visibility push(default)
 
 void *ref8_create(const rt_scene_desc *d) {
     Ref8 *r = new Ref8();
@@ -90,4 +91,5 @@ void ref8_tonemap(const float *rgb, uint8_t *out3) {
     auto a = toExternColorFormat(gamma_corrected(aces_tonemap(v3(rgb))));
     out3[0] = a[0]; out3[1] = a[1]; out3[2] = a[2];
 }
+#pragma GCC visibility pop
 }

@@ -310,10 +310,16 @@ struct Loader {
             for (const Prim &pr : meshes[*node.mesh]) {
                 if (pr.material >= hs->materials.size()) throw std::runtime_error("glTF: material index out of range");
                 std::vector<float> pos = load_floats(pr.position, 3), uv, nrm, tan;
+                size_t nv = pos.size() / 3;
                 if (full) {
-                    if (!pr.texcoord || !pr.normal || !pr.tangent)
-                        throw std::runtime_error("glTF: hw8 scenes need POSITION, TEXCOORD_0, NORMAL and TANGENT on every primitive (hw8/src/sceneio.cpp:88-91)");
-                    uv = load_floats(*pr.texcoord, 2); nrm = load_floats(*pr.normal, 3); tan = load_floats(*pr.tangent, 4);
+                    // The reference requires all four attributes (hw8/src/sceneio.cpp:88-91, it crashes
+                    // otherwise).  Extension: a missing TEXCOORD_0 reads as (0,0) and a missing TANGENT as
+                    // (1,0,0,1), which keeps the default normal-map sample an identity; NORMAL stays required.
+                    if (!pr.normal) throw std::runtime_error("glTF: hw8 scenes need NORMAL on every primitive (hw8/src/sceneio.cpp:90)");
+                    nrm = load_floats(*pr.normal, 3);
+                    if (pr.texcoord) uv = load_floats(*pr.texcoord, 2); else uv.assign(nv * 2, 0.f);
+                    if (pr.tangent) tan = load_floats(*pr.tangent, 4);
+                    else { tan.assign(nv * 4, 0.f); for (size_t v = 0; v < nv; v++) { tan[4 * v] = 1.f; tan[4 * v + 3] = 1.f; } }
                 }
                 size_t n_idx;
                 const Accessor &ia = accessors.at(pr.indices);
@@ -323,7 +329,6 @@ struct Loader {
                 const Mat4 &M = node.total;
                 Mat4 NM = M.inverted().transposed();
                 F3 shift = M.apply(F3{0, 0, 0});
-                size_t nv = pos.size() / 3;
                 for (size_t i = 0; i + 2 < n_idx; i += 3) {
                     size_t id[3];
                     for (int k = 0; k < 3; k++) {

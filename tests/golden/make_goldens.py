@@ -1,0 +1,43 @@
+"""Regenerates tests/golden/pins_*.npz from the compiled reference (oracle/_ref, needs /root/reference).
+Run:  python tests/golden/make_goldens.py      (after `make -C oracle`)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib  # noqa: E402
+import pin_cases  # noqa: E402
+
+
+def main():
+    L8 = C.CDLL(oracle_lib.ref_path("libref_hw8.so"))
+    L8.ref8_brdf.argtypes = [C.c_float] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
+    L8.ref8_tonemap.argtypes = [C.c_void_p, C.c_void_p]
+    # per-function pins through the reference's hw8 headers + primitives.cpp + color.cpp
+    for name, sd, seed in (("sphere", pin_cases.load_sphere(), 11), ("soup", pin_cases.random_triangle_scene(), 23)):
+        out = pin_cases.eval_functions(oracle_lib.Ref8(sd), sd, seed)
+        np.savez_compressed(os.path.join(HERE, f"pins_hw8_functions_{name}.npz"), **out)
+        print(name, {k: v.shape for k, v in out.items()})
+    bi = pin_cases.brdf_inputs()
+    br = np.stack([oracle_lib.brdf(L8, "ref8_", float(bi["base_metallic"][i]), bi["base_color"][i], bi["l"][i], bi["v"][i], bi["n"][i],
+                                   bi["color"][i], float(bi["metallic"][i]), float(bi["alpha"][i])) for i in range(len(bi["alpha"]))])
+    ti = pin_cases.tonemap_inputs()
+    tm = np.stack([oracle_lib.tonemap(L8, "ref8_tonemap", ti[i]) for i in range(len(ti))])
+    np.savez_compressed(os.path.join(HERE, "pins_hw8_brdf_tonemap.npz"), brdf=br, tonemap=tm)
+    # whole-integrator pins through the reference's hw7 scene.cpp (Scene::getPixel)
+    cases = {"practice7_1": (pin_cases.load_hw7("practice7_1"), 48, 48, 8), "practice7_4": (pin_cases.load_hw7("practice7_4"), 48, 48, 8),
+             "sphere_as_hw7": (pin_cases.as_hw7(pin_cases.load_sphere()), 40, 40, 6), "soup_as_hw7": (pin_cases.as_hw7(pin_cases.random_triangle_scene()), 40, 32, 6)}
+    out = {}
+    for name, (sd, w, h, spp) in cases.items():
+        rgb, rgb8, _ = oracle_lib.Ref7(sd).render(w, h, spp)
+        out[name + "_rgb"], out[name + "_rgb8"] = rgb, rgb8
+        print(name, rgb.shape, float(rgb.mean()))
+    np.savez_compressed(os.path.join(HERE, "pins_hw7_render.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""ctypes access to the CPU oracle (oracle/_build/liboracle.so) and, when built, the reference harnesses
+(oracle/_ref/*.so).  Test infrastructure only: nothing in the product imports this."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+rt = importlib.import_module("raytracing-course-hw_amd")
+
+
+class Counters(C.Structure):
+    _fields_ = [("closest", C.c_uint64), ("lightq", C.c_uint64), ("boxes", C.c_uint64), ("tris", C.c_uint64)]
+
+
+def _build():
+    so = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_hw8.cpp", "oracle_common.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "_build/liboracle.so"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(_build())
+        for name in ("rto_hw8_create", "rto_hw7_create"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.rto_hw8_destroy.argtypes = [C.c_void_p]
+        L.rto_hw8_render.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Counters)]
+        L.rto_hw8_num_lights.argtypes = [C.c_void_p]
+        L.rto_hw8_num_lights.restype = C.c_uint32
+        L.rto_hw8_light_order.argtypes = [C.c_void_p, C.c_void_p]
+        L.rto_hw8_figure_order.argtypes = [C.c_void_p, C.c_void_p]
+        L.rto_hw8_bvh_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.rto_hw8_closest_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rto_hw8_light_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rto_hw8_light_pdf.restype = C.c_float
+        L.rto_hw8_mix_sample_pdf.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.rto_hw8_brdf.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.rto_tonemap.argtypes = [C.c_void_p, C.c_void_p]
+        L.rto_sample_texture.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.rto_rng_kat.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.rto_rng_kat_normals_first.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _f3(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Hw8Oracle:
+    """CPU restatement of the hw8 path (oracle/oracle_hw8.cpp); hw7=True selects the hw7 replay mode."""
+
+    def __init__(self, scene_data, hw7=False):
+        self.data = scene_data
+        L = lib()
+        self._h = (L.rto_hw7_create if hw7 else L.rto_hw8_create)(C.byref(scene_data.desc))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rto_hw8_destroy(self._h)
+            self._h = None
+
+    def render(self, width, height, samples, ray_depth=0, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        cnt = Counters()
+        lib().rto_hw8_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data,
+                             threads, C.byref(cnt))
+        return rgb, rgb8, cnt
+
+    def light_order(self):
+        n = lib().rto_hw8_num_lights(self._h)
+        out = np.zeros(max(n, 1), np.uint32)
+        lib().rto_hw8_light_order(self._h, out.ctypes.data)
+        return out[:n]
+
+    def figure_order(self):
+        out = np.zeros(max(self.data.positions.shape[0], 1), np.uint32)
+        lib().rto_hw8_figure_order(self._h, out.ctypes.data)
+        return out[:self.data.positions.shape[0]]
+
+    def bvh_stats(self):
+        out = np.zeros(4, np.uint32)
+        lib().rto_hw8_bvh_stats(self._h, out.ctypes.data)
+        return out
+
+    def closest_hit(self, o, d):
+        out = np.zeros(14, np.float32)
+        idx = lib().rto_hw8_closest_hit(self._h, _f3(o).ctypes.data, _f3(d).ctypes.data, out.ctypes.data)
+        return idx, out
+
+    def light_pdf(self, x, d):
+        return lib().rto_hw8_light_pdf(self._h, _f3(x).ctypes.data, _f3(d).ctypes.data)
+
+    def mix_sample_pdf(self, seed, x, n, v, alpha):
+        out = np.zeros(5, np.float32)
+        lib().rto_hw8_mix_sample_pdf(self._h, seed, _f3(x).ctypes.data, _f3(n).ctypes.data, _f3(v).ctypes.data, alpha, out.ctypes.data)
+        return out
+
+
+# ---- reference harnesses (only where oracle/_ref was built, i.e. a container with /root/reference) ----
+def ref_path(name):
+    p = os.path.join(ORACLE_DIR, "_ref", name)
+    return p if os.path.exists(p) else None
+
+
+class Ref8:
+    """The reference's own hw8 functions (oracle/_ref/libref_hw8.so, built from /root/reference)."""
+
+    def __init__(self, scene_data):
+        p = ref_path("libref_hw8.so")
+        if p is None:
+            raise FileNotFoundError("oracle/_ref/libref_hw8.so not built")
+        L = C.CDLL(p)
+        L.ref8_create.restype = C.c_void_p
+        L.ref8_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.ref8_destroy.argtypes = [C.c_void_p]
+        L.ref8_figure_order.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref8_closest_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref8_light_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref8_light_pdf.restype = C.c_float
+        L.ref8_mix_sample_pdf.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.ref8_brdf.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.ref8_tonemap.argtypes = [C.c_void_p, C.c_void_p]
+        self.L, self.data = L, scene_data
+        self._h = L.ref8_create(C.byref(scene_data.desc))
+
+    def figure_order(self):
+        out = np.zeros(self.data.positions.shape[0], np.uint32)
+        self.L.ref8_figure_order(self._h, out.ctypes.data)
+        return out
+
+    def closest_hit(self, o, d):
+        out = np.zeros(14, np.float32)
+        idx = self.L.ref8_closest_hit(self._h, _f3(o).ctypes.data, _f3(d).ctypes.data, out.ctypes.data)
+        return idx, out
+
+    def light_pdf(self, x, d):
+        return self.L.ref8_light_pdf(self._h, _f3(x).ctypes.data, _f3(d).ctypes.data)
+
+    def mix_sample_pdf(self, seed, x, n, v, alpha):
+        out = np.zeros(5, np.float32)
+        self.L.ref8_mix_sample_pdf(self._h, seed, _f3(x).ctypes.data, _f3(n).ctypes.data, _f3(v).ctypes.data, alpha, out.ctypes.data)
+        return out
+
+
+class Ref7:
+    """The reference's own hw7 integrator (oracle/_ref/libref_hw7.so: hw7 scene.cpp/primitives.cpp/color.cpp)."""
+
+    def __init__(self, scene_data):
+        p = ref_path("libref_hw7.so")
+        if p is None:
+            raise FileNotFoundError("oracle/_ref/libref_hw7.so not built")
+        L = C.CDLL(p)
+        L.ref7_create.restype = C.c_void_p
+        L.ref7_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.ref7_render.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int]
+        self.L, self.data = L, scene_data
+        self._h = L.ref7_create(C.byref(scene_data.desc))
+
+    def render(self, width, height, samples, ray_depth=0, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        self.L.ref7_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
+        return rgb, rgb8, None
+
+
+def brdf(impl_lib, prefix, base_metallic, base_color, l, v, n, color, metallic, alpha):
+    out = np.zeros(3, np.float32)
+    getattr(impl_lib, prefix + "brdf")(base_metallic, _f3(base_color).ctypes.data, _f3(l).ctypes.data, _f3(v).ctypes.data,
+                                       _f3(n).ctypes.data, _f3(color).ctypes.data, metallic, alpha, out.ctypes.data)
+    return out
+
+
+def tonemap(impl_lib, name, rgb):
+    out = np.zeros(3, np.uint8)
+    getattr(impl_lib, name)(_f3(rgb).ctypes.data, out.ctypes.data)
+    return out

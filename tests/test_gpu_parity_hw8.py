@@ -1,0 +1,35 @@
+"""GPU parity: the HIP render path (through the C-ABI) against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+# Tolerance from BASELINE.json north_star: per-pixel RMSE < 1e-3 on linear radiance vs the CPU reference.
+RMSE_TOL = 1e-3
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+@pytest.mark.parametrize("size,spp", [((64, 64), 4), ((96, 64), 16)])
+def test_sphere_emissive_matches_oracle(rt, sphere_scene, size, spp):
+    w, h = size
+    scene = rt.Scene(sphere_scene)
+    rgb, rgb8, st = scene.render(w, h, spp)
+    ref, ref8, _ = oracle_lib.Hw8Oracle(sphere_scene).render(w, h, spp)
+    rmse = _rmse(rgb, ref)
+    bad = int((np.abs(rgb - ref).max(axis=2) > 1e-3).sum())
+    print(f"{w}x{h}x{spp}: rmse {rmse:.3e}, desync pixels {bad}, byte mismatches {(rgb8 != ref8).sum()}, exact {np.array_equal(rgb, ref)}")
+    assert rmse < RMSE_TOL
+    assert bad <= max(1, (w * h) // 2000)
+    assert (rgb8 != ref8).sum() <= max(3, (w * h * 3) // 1000)
+    scene.close()
+
+
+def test_light_order_matches_oracle(rt, sphere_scene):
+    scene = rt.Scene(sphere_scene)
+    assert np.array_equal(scene.light_order(), oracle_lib.Hw8Oracle(sphere_scene).light_order())
+    scene.close()

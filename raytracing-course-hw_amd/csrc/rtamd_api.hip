@@ -15,6 +15,8 @@
 #include "host/png.h"
 #include "host/scene_prep.h"
 #include "device/rt_kernels_hw8.h"
+#include "device/rt_wavefront.h"
+#include <cstdlib>
 
 namespace rtamd {
 static thread_local std::string g_last_error;
@@ -70,7 +72,17 @@ struct rt_scene {
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int n_cus = 256;
+    // wavefront path state (grown on demand, reused across renders)
+    dev::WfView wf{};
+    size_t wf_slots = 0, wf_levels = 0, wf_rounds = 0;
+    std::vector<void *> wf_allocs;
+    void free_wf() {
+        for (void *p : wf_allocs) (void)hipFree(p);
+        wf_allocs.clear();
+        wf_slots = wf_levels = wf_rounds = 0;
+    }
     ~rt_scene() {
+        free_wf();
         for (void *p : allocations) (void)hipFree(p);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
@@ -200,6 +212,41 @@ size_t rt_output_elems(const rt_render_params *p) {
     return (size_t)R.width * R.height * 3;
 }
 
+// Wavefront driver: spp * ray_depth rounds of trace / shade / light / update (device/rt_wavefront.h).
+// No host synchronisation inside: queue lengths live in device memory, one counter block per round.
+static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count) {
+    const size_t n_slots = (size_t)n_work * 64;
+    const size_t rounds = (size_t)R.samples * R.ray_depth;
+    if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_rounds < rounds) {
+        scene->free_wf();
+        auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); scene->wf_allocs.push_back(p); return p; };
+        scene->wf.r0 = (float4 *)alloc(n_slots * 64);
+        scene->wf.stack = (float4 *)alloc(n_slots * 32 * (size_t)R.ray_depth);
+        scene->wf.q_trace[0] = (uint32_t *)alloc(n_slots * 4);
+        scene->wf.q_trace[1] = (uint32_t *)alloc(n_slots * 4);
+        scene->wf.q_light = (uint32_t *)alloc(n_slots * 4);
+        scene->wf.ctr = (uint32_t *)alloc((rounds + 2) * 16);
+        scene->wf_slots = n_slots; scene->wf_levels = (size_t)R.ray_depth; scene->wf_rounds = rounds;
+    }
+    dev::WfView W = scene->wf;
+    W.n_slots = (uint32_t)n_slots;
+    HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * 16, stream));
+    const uint32_t persistent_blocks = (uint32_t)scene->n_cus * 5u;   // 5 x 256 threads x 32 KB LDS per CU
+    uint32_t shade_blocks = (uint32_t)((n_slots + 255) / 256);
+    if (shade_blocks > (uint32_t)scene->n_cus * 16u) shade_blocks = (uint32_t)scene->n_cus * 16u;
+    unsigned long long *ctrs = count ? scene->d_counters : nullptr;
+    hipLaunchKernelGGL(dev::wf_init_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream, scene->view, R, W);
+    for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
+        if (count) hipLaunchKernelGGL(dev::wf_trace_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
+        else hipLaunchKernelGGL(dev::wf_trace_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
+        hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
+        if (count) hipLaunchKernelGGL(dev::wf_light_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
+        else hipLaunchKernelGGL(dev::wf_light_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
+        hipLaunchKernelGGL(dev::wf_update_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
@@ -236,11 +283,23 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 32, stream));
         uint32_t blocks = (uint32_t)scene->n_cus * 16u;
         if (blocks > n_work) blocks = n_work;
+        // Kernel organisation: "wavefront" (default) or the single persistent "megakernel" (RTAMD_KERNEL=mega,
+        // also the fallback when a BVH is deeper than the wavefront kernels' LDS stacks).
+        const char *ksel = getenv("RTAMD_KERNEL");
+        bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
+        if (scene->info.bvh_depth > WF_STACK || scene->info.light_bvh_depth > WF_STACK || scene->info.n_triangles >= 0x40000000u) use_wavefront = false;
+        uint32_t launches = 0;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
-            if (count) hipLaunchKernelGGL(dev::render_hw8_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
-            else hipLaunchKernelGGL(dev::render_hw8_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
-            HIP_CHECK(hipGetLastError());
+            if (use_wavefront) {
+                launch_wavefront(scene, R, n_work, stream, count);
+                launches = 1 + 4 * (uint32_t)R.samples * (uint32_t)R.ray_depth;
+            } else {
+                if (count) hipLaunchKernelGGL(dev::render_hw8_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
+                else hipLaunchKernelGGL(dev::render_hw8_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
+                HIP_CHECK(hipGetLastError());
+                launches = 1;
+            }
         }
         HIP_CHECK(hipEventRecord(scene->ev_stop, stream));
         if (own_rgb) HIP_CHECK(hipMemcpyAsync(out_rgb, d_rgb, elems * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -248,6 +307,12 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         unsigned long long h_cnt[4] = {0, 0, 0, 0};
         if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 32, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
+        if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
+            size_t rounds = (size_t)R.samples * R.ray_depth;
+            std::vector<uint32_t> ctr((rounds + 2) * 4);
+            HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t r = 0; r < rounds; r++) { h_cnt[0] += ctr[4 * r]; if (scene->info.n_lights) h_cnt[1] += ctr[4 * r + 1]; }
+        }
         if (own_rgb) { (void)hipFree(d_rgb); own_rgb = false; }
         if (own_rgb8) { (void)hipFree(d_rgb8); own_rgb8 = false; }
         if (stats) {
@@ -256,7 +321,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             memset(stats, 0, sizeof *stats);
             stats->kernel_ms = ms;
             stats->total_ms = now_ms() - t0;
-            stats->launches = blocks ? 1 : 0;
+            stats->launches = launches;
             // pixels of this shard that lie inside the image
             uint64_t px = 0;
             for (uint32_t st = 0; st < R.n_shard_tiles; st++) {

@@ -14,8 +14,15 @@ def _rmse(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-@pytest.mark.parametrize("size,spp", [((64, 64), 4), ((96, 64), 16)])
-def test_sphere_emissive_matches_oracle(rt, sphere_scene, size, spp):
+@pytest.fixture(params=["wavefront", "mega"])
+def kernel(request, monkeypatch):
+    """Both kernel organisations must give the same pixels (RTAMD_KERNEL is read at render time)."""
+    monkeypatch.setenv("RTAMD_KERNEL", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("size,spp", [((64, 64), 4), ((96, 64), 16), ((70, 45), 3)])
+def test_sphere_emissive_matches_oracle(rt, sphere_scene, kernel, size, spp):
     w, h = size
     scene = rt.Scene(sphere_scene)
     rgb, rgb8, st = scene.render(w, h, spp)

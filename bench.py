@@ -87,24 +87,14 @@ def main():
     n_elems = rt.lib.rt_output_elems(params)
     out_rgb = torch.zeros(n_elems, dtype=torch.float32, device="cuda")
     out_rgb8 = torch.zeros(n_elems, dtype=torch.uint8, device="cuda")
-    gather_list = None
-    if world > 1:
-        # every shard buffer has the same length except possibly the last ranks: pad to the maximum
-        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n_elems], dtype=torch.int64, device="cuda"))
-        max_elems = int(max(int(s.item()) for s in sizes))
-        send = torch.zeros(max_elems, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            gather_list = [torch.zeros(max_elems, dtype=torch.uint8, device="cuda") for _ in range(world)]
-
+    rtd = importlib.import_module("raytracing-course-hw_amd.distributed")
     kernel_ms = []
 
     def step():
-        # the tonemapped tiles land directly in the (padded) send buffer when sharded
-        st = scene.render_device(params, out_rgb.data_ptr(), send.data_ptr() if world > 1 else out_rgb8.data_ptr())
+        st = scene.render_device(params, out_rgb.data_ptr(), out_rgb8.data_ptr())
         kernel_ms.append(st.kernel_ms)
-        if world > 1:  # the one exchange step: tonemapped tiles to rank 0 over RCCL/xGMI
-            dist.gather(send, gather_list, dst=0)
+        if world > 1:  # the one exchange step: tonemapped tiles to rank 0 over RCCL/xGMI, assembled into the frame there
+            rtd.gather_frame(dist, out_rgb8, W, H, SPP, rank, world, 32)
         return st
 
     for _ in range(args.warmup):

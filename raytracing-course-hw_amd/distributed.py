@@ -1,0 +1,41 @@
+"""Multi-GPU frame assembly: one process per GPU, pixel tiles dealt round-robin, ONE exchange step.
+
+Every rank renders the tiles  t % world == rank  into a compact shard buffer (layout in include/rtamd.h);
+rank 0 gathers the buffers (torch.distributed gather: RCCL over xGMI on GPUs, gloo in the CPU tests) and
+scatters them into the full frame.  Rendering needs no collective: the per-pixel seed y*W+x is global, so any
+partition produces the same pixels (reference: hw8/src/sceneio.cpp:389-391)."""
+import importlib
+
+import numpy as np
+
+rt = importlib.import_module(__name__.rsplit(".", 1)[0])
+
+
+def shard_params(width, height, samples, rank, world, tile=32, **kw):
+    return rt.make_params(width, height, samples, shard_index=rank, shard_count=world, tile=tile, **kw)
+
+
+def shard_elems(width, height, samples, world, tile=32):
+    """Output elements of every rank's shard buffer."""
+    return [int(rt.lib.rt_output_elems(shard_params(width, height, samples, r, world, tile))) for r in range(world)]
+
+
+def gather_frame(dist, local, width, height, samples, rank, world, tile=32):
+    """local: 1-D torch tensor holding this rank's shard buffer (u8 or f32).  Returns the full (H, W, 3) numpy
+    frame on rank 0 and None elsewhere."""
+    import torch
+    sizes = shard_elems(width, height, samples, world, tile)
+    pad = max(sizes)
+    send = local
+    if local.numel() != pad:
+        send = torch.zeros(pad, dtype=local.dtype, device=local.device)
+        send[:local.numel()] = local
+    bufs = [torch.zeros(pad, dtype=local.dtype, device=local.device) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, bufs, dst=0)
+    if rank != 0:
+        return None
+    frame = np.zeros((height, width, 3), dtype=np.uint8 if local.dtype == torch.uint8 else np.float32)
+    for r in range(world):
+        part = rt.unshard(shard_params(width, height, samples, r, world, tile), bufs[r][:sizes[r]].cpu().numpy())
+        frame += part  # shards are disjoint; untouched pixels of a part are zero
+    return frame

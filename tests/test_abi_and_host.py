@@ -1,0 +1,90 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/rtamd.h declares, the host
+front-end (glTF/PNG loader, PPM writer, shard layout) behaves, and GPU entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(rt):
+    header = open(os.path.join(ROOT, "include", "rtamd.h")).read()
+    declared = set(re.findall(r"^(?:int|void|size_t|const char \*|const rt_scene_desc \*)\s*(rt_[a-z0-9_]+)\(", header, re.M))
+    assert len(declared) >= 17
+    assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(rt.lib, name), f"librtamd.so does not export {name}"
+    assert rt.lib.rt_abi_version() == 1
+
+
+def test_struct_sizes_match_header(rt):
+    # sizes the C side checks through struct_size; a mismatch means the ctypes mirror drifted
+    assert C.sizeof(rt.rt_material) == 56 and C.sizeof(rt.rt_render_params) == 56
+    assert C.sizeof(rt.rt_scene_desc) % 8 == 0
+
+
+def test_gltf_loader_sphere(rt, sphere_scene):
+    sd = sphere_scene
+    assert sd.positions.shape == (970, 9) and sd.n_materials == 2 and len(sd.images) == 1
+    assert sd.images[0].shape == (1024, 1024, 3)
+    assert sd.materials[1].emissive_texture == 0 and list(sd.materials[1].emission) == [5.0, 5.0, 5.0]  # strength 5 applied
+    assert abs(sd.camera.fov_y - 1.0521329641342163) < 1e-7 and list(sd.camera.position) == [0.0, 0.0, pytest.approx(5.149219512939453)]
+    n = sd.normals.reshape(-1, 3)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-5)
+
+
+def test_loader_errors_are_reported_not_crashes(rt, tmp_path):
+    with pytest.raises(rt.RtError):
+        rt.load_gltf(str(tmp_path / "missing.gltf"))
+    bad = tmp_path / "bad.gltf"
+    bad.write_text('{"buffers": [{"byteLength": 4, "uri": "nope.bin"}]}')
+    with pytest.raises(rt.RtError):
+        rt.load_gltf(str(bad))
+    bad.write_text("{ not json")
+    with pytest.raises(rt.RtError):
+        rt.load_gltf(str(bad))
+
+
+def test_ppm_writer_and_png_decoder(rt, tmp_path):
+    img = (np.arange(5 * 7 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
+    p = tmp_path / "o.ppm"
+    rt.write_ppm(str(p), img)
+    data = p.read_bytes()
+    assert data.startswith(b"P6\n7 5\n255\n") and data[len(b"P6\n7 5\n255\n"):] == img.tobytes()  # hw8/src/sceneio.cpp:383-385
+    tex = rt.decode_png(os.path.join(ROOT, "tests", "golden", "scenes", "hw8_sphere", "sphere_emission.png"))
+    assert tex.shape == (1024, 1024, 3) and tex.dtype == np.uint8 and tex.max() > 0
+
+
+def test_shard_layout_roundtrip(rt):
+    W, H = 70, 45
+    full = np.random.default_rng(0).integers(0, 255, (H, W, 3)).astype(np.uint8)
+    acc = np.zeros_like(full)
+    for world in (2, 3):
+        acc[:] = 0
+        for r in range(world):
+            p = rt.make_params(W, H, 1, shard_index=r, shard_count=world, tile=16)
+            n = rt.lib.rt_output_elems(p)
+            tiles_x = (W + 15) // 16
+            buf = np.zeros(n, np.uint8)
+            st = 0
+            for t in range(r, tiles_x * ((H + 15) // 16), world):
+                x0, y0 = (t % tiles_x) * 16, (t // tiles_x) * 16
+                tile = np.zeros((16, 16, 3), np.uint8)
+                w, h = min(16, W - x0), min(16, H - y0)
+                tile[:h, :w] = full[y0:y0 + h, x0:x0 + w]
+                buf[st * 768:(st + 1) * 768] = tile.reshape(-1)
+                st += 1
+            acc += rt.unshard(p, buf)
+        assert np.array_equal(acc, full)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(rt, sphere_scene):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene(sphere_scene)
+    assert e.value.code == rt.RT_ERR_NO_DEVICE

@@ -37,6 +37,13 @@ def main():
         out[name + "_rgb"], out[name + "_rgb8"] = rgb, rgb8
         print(name, rgb.shape, float(rgb.mean()))
     np.savez_compressed(os.path.join(HERE, "pins_hw7_render.npz"), **out)
+    # whole-integrator pins through the reference's hw6 scene.cpp (dielectric recursion, Mix{Cosine, lights})
+    out = {}
+    for name, (mk, w, h, spp) in pin_cases.HW6_CASES.items():
+        rgb, rgb8, _ = oracle_lib.Ref6(mk()).render(w, h, spp)
+        out[name + "_rgb"], out[name + "_rgb8"] = rgb, rgb8
+        print(name, rgb.shape, float(rgb.mean()))
+    np.savez_compressed(os.path.join(HERE, "pins_hw6_render.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -189,3 +189,78 @@ def tonemap(impl_lib, name, rgb):
     out = np.zeros(3, np.uint8)
     getattr(impl_lib, name)(_f3(rgb).ctypes.data, out.ctypes.data)
     return out
+
+
+def _setup_hw6(L):
+    if getattr(L, "_hw6_ready", False):
+        return
+    L.rto_hw6_create.restype = C.c_void_p
+    L.rto_hw6_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+    L.rto_hw6_destroy.argtypes = [C.c_void_p]
+    L.rto_hw6_render.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Counters)]
+    L.rto_hw6_num_lights.argtypes = [C.c_void_p]
+    L.rto_hw6_num_lights.restype = C.c_uint32
+    L.rto_hw6_light_order.argtypes = [C.c_void_p, C.c_void_p]
+    L.rto_hw6_figure_order.argtypes = [C.c_void_p, C.c_void_p]
+    L.rto_hw6_bvh_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L._hw6_ready = True
+
+
+class Hw6Oracle:
+    """CPU restatement of the hw6 path (oracle/oracle_hw6.cpp)."""
+
+    def __init__(self, scene_data):
+        self.data = scene_data
+        _setup_hw6(lib())
+        self._h = lib().rto_hw6_create(C.byref(scene_data.desc))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rto_hw6_destroy(self._h)
+            self._h = None
+
+    def render(self, width, height, samples, ray_depth=0, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        cnt = Counters()
+        lib().rto_hw6_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads, C.byref(cnt))
+        return rgb, rgb8, cnt
+
+    def light_order(self):
+        n = lib().rto_hw6_num_lights(self._h)
+        out = np.zeros(max(n, 1), np.uint32)
+        lib().rto_hw6_light_order(self._h, out.ctypes.data)
+        return out[:n]
+
+    def figure_order(self):
+        out = np.zeros(max(self.data.positions.shape[0], 1), np.uint32)
+        lib().rto_hw6_figure_order(self._h, out.ctypes.data)
+        return out[:self.data.positions.shape[0]]
+
+    def bvh_stats(self):
+        out = np.zeros(4, np.uint32)
+        lib().rto_hw6_bvh_stats(self._h, out.ctypes.data)
+        return out
+
+
+class Ref6:
+    """The reference's own hw6 integrator (oracle/_ref/libref_hw6.so: hw6 scene.cpp/primitives.cpp/color.cpp)."""
+
+    def __init__(self, scene_data):
+        p = ref_path("libref_hw6.so")
+        if p is None:
+            raise FileNotFoundError("oracle/_ref/libref_hw6.so not built")
+        L = C.CDLL(p)
+        L.ref6_create.restype = C.c_void_p
+        L.ref6_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.ref6_render.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int]
+        self.L, self.data = L, scene_data
+        self._h = L.ref6_create(C.byref(scene_data.desc))
+
+    def render(self, width, height, samples, ray_depth=0, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        self.L.ref6_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
+        return rgb, rgb8, None

@@ -115,3 +115,21 @@ def tonemap_inputs(seed=6, k=3000):
     rng = np.random.default_rng(seed)
     x = np.concatenate([rng.uniform(0, 1.5, (k, 3)), rng.exponential(2.0, (k // 3, 3)), np.zeros((1, 3)), np.full((1, 3), 1e-8)])
     return x.astype(np.float32)
+
+
+def load_hw6(name):
+    return rt.load_gltf(os.path.join(SCENES, "hw6", name + ".gltf"), rt.RT_INTEGRATOR_HW6)
+
+
+def hw6_soup(n=300, seed=17):
+    """Triangle soup with all three hw6 material kinds (dielectric recursion included) and emissive triangles."""
+    sd = random_triangle_scene(n, seed, n_emissive_mats=1)
+    kinds = [0, 0, 1, 2, 2, 0]  # RT_MAT_DIFFUSE / METALLIC / DIELECTRIC
+    for i in range(sd.n_materials):
+        sd.materials[i].kind = kinds[i]
+        sd.materials[i].ior = 1.5
+    return rt.SceneData(sd.positions, None, None, None, sd.material_index, list(sd.materials)[:sd.n_materials], camera=sd.camera, bg=(0.1, 0.2, 0.3))
+
+
+HW6_CASES = {"practice6_1": (lambda: load_hw6("practice6_1"), 48, 36, 4), "practice6_2": (lambda: load_hw6("practice6_2"), 20, 20, 2),
+             "hw6_soup": (hw6_soup, 48, 40, 8)}

@@ -60,6 +60,18 @@ def test_hw7_whole_integrator_bit_exact(name, w, h, spp):
     assert same(rgb8, gold[name + "_rgb8"])
 
 
+@pytest.mark.parametrize("name", sorted(pin_cases.HW6_CASES))
+def test_hw6_whole_integrator_bit_exact(name):
+    """Scene::getPixel of the compiled hw6 reference (dielectric recursion tree, mirror, Mix{Cosine, FiguresMix}) vs
+    oracle/oracle_hw6.cpp."""
+    mk, w, h, spp = pin_cases.HW6_CASES[name]
+    rgb, rgb8, _ = oracle_lib.Hw6Oracle(mk()).render(w, h, spp)
+    gold = np.load(os.path.join(GOLD, "pins_hw6_render.npz"))
+    assert gold[name + "_rgb"].mean() > 0.01
+    assert same(rgb, gold[name + "_rgb"]), f"{name}: linear radiance differs from the reference"
+    assert same(rgb8, gold[name + "_rgb8"])
+
+
 def test_hw8_sphere_matches_reference_values_recorded_in_survey():
     """SURVEY.md §8(c) records three pixels of the compiled hw8 reference (sphere_emissive, 64x64, 4 spp,
     through the public Scene::getPixel).  They cover the full hw8 getColor, incl. the emissive texture."""

@@ -1,0 +1,274 @@
+// hw6 render kernel (BASELINE.json configs[2]): glTF triangles with flat normals, DIFFUSE / METALLIC(mirror) /
+// DIELECTRIC(ior 1.5) materials, Mix{Cosine, FiguresMix}, and the dielectric branch's binary recursion
+// (hw6/src/scene.cpp:47-105), replayed per pixel with the reference's minstd_rand stream.
+//
+// The recursion tree (reflected subtree first, then one uniform, then maybe the refracted subtree;
+// <= 2^depth - 1 rays per camera sample) is evaluated with an explicit per-lane frame stack.
+// The scene BVH is NOT the reference's (its sort key is a constant, hw6/src/include/bvh.h:61-63, which
+// degenerates the tree); figures keep their index in the reference's order for the tie rule, the light BVH
+// keeps the reference's topology because its shape fixes the order of the float additions.
+#pragma once
+#include "rt_device.h"
+#include "rt_types_hw6.h"
+
+namespace rtamd {
+
+namespace dev {
+
+#define RT6_MAX_DEPTH 8
+#define RT6_STACK_SIZE 128 // hw6's light tree is built on a constant sort key and can be very deep (practice6_2: 85)
+#define RT_PI_F 3.14159274101257324219f // const float PI = acos(-1), hw6/src/include/distributions.h:11
+
+struct Tri6Regs { F3 a, b, c, n; uint32_t ref_index, last, material; float point_prob; };
+RT_DEV Tri6Regs load_tri6(const Tri6 *p) {
+    const float4 *q = reinterpret_cast<const float4 *>(p);
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    Tri6Regs T;
+    T.a = f3(q0.x, q0.y, q0.z); T.b = f3(q0.w, q1.x, q1.y); T.c = f3(q1.z, q1.w, q2.x); T.n = f3(q2.y, q2.z, q2.w);
+    T.ref_index = __float_as_uint(q3.x); T.last = __float_as_uint(q3.y); T.material = __float_as_uint(q3.z); T.point_prob = q3.w;
+    return T;
+}
+// hw6/src/primitives.cpp:77-86,143-164 (position 0 / identity rotation: the figure transform is the identity).
+RT_DEV bool tri6_test(const Tri6Regs &T, F3 o, F3 d, float &t, bool &inside) {
+    F3 ro = o - T.a;
+    float dn = dot(d, T.n);
+    t = -dot(ro, T.n) / dn;
+    if (!(t > 0 && t < RT_T_MAX)) return false;
+    inside = dn > 0;
+    F3 p = ro + t * d;
+    if (dot(crossr(T.b, p), T.n) < 0) return false;
+    if (dot(crossr(p, T.c), T.n) < 0) return false;
+    if (dot(crossr(T.c - T.b, p - T.b), T.n) < 0) return false;
+    return true;
+}
+
+struct Hit6 { int slot; float t; bool inside; uint32_t ref; };
+
+RT_DEV Hit6 closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack) {
+    Hit6 best; best.slot = -1; best.t = RT_T_MAX; best.inside = false; best.ref = 0xFFFFFFFFu;
+    RayInv ray = make_ray_inv(o, d);
+    int sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        if (!(cur & RT_LEAF_BIT)) {
+            const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
+            float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+            float n0, n1;
+            bool h0 = slab_test(lo0, hi0, ray, best.t, n0);
+            bool h1 = slab_test(lo1, hi1, ray, best.t, n1);
+            uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+            if (h0 & h1) { bool swap = n1 < n0; stack[sp++] = swap ? c0 : c1; cur = swap ? c1 : c0; continue; }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else if (cur != RT_EMPTY_LEAF) {
+            uint32_t i = cur & ~RT_LEAF_BIT;
+            for (;;) {
+                Tri6Regs T = load_tri6(S.tris + i);
+                float t; bool inside;
+                // reference tie rule: smallest t, equal t -> lowest index in the reference's figure order
+                if (tri6_test(T, o, d, t, inside) && (t < best.t || (t == best.t && T.ref_index < best.ref))) {
+                    best.t = t; best.inside = inside; best.slot = (int)i; best.ref = T.ref_index;
+                }
+                if (T.last) break;
+                i++;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return best;
+}
+
+// FiguresMix::getTotalPdf for triangle lights (hw6/src/include/distributions.h:212-256), reference addition tree.
+RT_DEV float light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
+    RayInv ray = make_ray_inv(x, d);
+    int sp = 0;
+    unsigned long long mask_lo = 0, mask_hi = 0; // frame kind per stack slot: 1 = ADD(partial sum), 0 = TODO(child)
+    uint32_t cur = 0;
+    bool descending = true;
+    float v = 0.f;
+    for (;;) {
+        if (descending) {
+            if (cur & RT_LEAF_BIT) {
+                float result = 0.f;
+                if (cur != RT_EMPTY_LEAF) {
+                    uint32_t i = cur & ~RT_LEAF_BIT;
+                    for (;;) {
+                        Tri6Regs T = load_tri6(S.lights + i);
+                        float t; bool inside; float term = 0.f;
+                        if (tri6_test(T, x, d, t, inside)) {
+                            F3 yn = normalize(inside ? neg(T.n) : T.n);            // primitives.cpp:31
+                            F3 y = x + t * d;
+                            term = T.point_prob * len2(x - y) / fabsf(dot(d, yn)); // distributions.h:116-118
+                        }
+                        result += term;
+                        if (T.last) break;
+                        i++;
+                    }
+                }
+                v = result; descending = false; continue;
+            }
+            const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
+            float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+            float n0, n1;
+            bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
+            bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+            uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+            if (h0 & h1) {
+                if (sp < 64) mask_lo &= ~(1ull << sp); else mask_hi &= ~(1ull << (sp - 64));
+                stack[sp++] = c1; cur = c0;
+            }
+            else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else { v = 0.f; descending = false; }
+        } else {
+            if (sp == 0) break;
+            --sp;
+            uint32_t f = stack[sp];
+            bool is_add = sp < 64 ? ((mask_lo >> sp) & 1ull) != 0 : ((mask_hi >> (sp - 64)) & 1ull) != 0;
+            if (is_add) v = __uint_as_float(f) + v;
+            else {
+                if (sp < 64) mask_lo |= 1ull << sp; else mask_hi |= 1ull << (sp - 64);
+                stack[sp++] = __float_as_uint(v); cur = f; descending = true;
+            }
+        }
+    }
+    return v;
+}
+
+enum { F6_MUL = 0, F6_DIEL_REFLECT = 1, F6_DIEL_REFRACT = 2 };
+struct Frame6 {
+    F3 emission, mult;    // F6_MUL: result = emission + mult * child ; DIEL frames: mult = material colour
+    F3 x, dn, norma;      // hit point (ray.o + t*ray.d), normalised incoming direction, normal
+    int kind; bool inside; float ior;
+};
+
+// Scene::getColor of hw6 as an explicit stack machine.
+RT_DEV F3 trace_tree6(const SceneView6 &S, int ray_depth, Rng &rng, F3 o, F3 d, uint32_t *stack) {
+    Frame6 frames[RT6_MAX_DEPTH];
+    int fp = 0;
+    const float epsf = 9.99999974737875163555e-05f; // (float)1e-4L
+    F3 ret = f3(0.f, 0.f, 0.f);
+    bool evaluating = true; // true: evaluate getColor(o, d, ray_depth - fp) ; false: `ret` is a finished child value
+    for (;;) {
+        if (evaluating) {
+            if (fp >= ray_depth) { ret = f3(0.f, 0.f, 0.f); evaluating = false; continue; }   // recLimit == 0
+            Hit6 h = closest_hit6(S, o, d, stack);
+            if (h.slot < 0) { ret = f3(S.bg); evaluating = false; continue; }
+            Tri6Regs T = load_tri6(S.tris + h.slot);
+            const float4 *qm = reinterpret_cast<const float4 *>(S.materials + T.material);
+            float4 m0 = qm[0], m1 = qm[1];
+            F3 color = f3(m0.x, m0.y, m0.z), emission = f3(m1.x, m1.y, m1.z);
+            int kind = (int)__float_as_uint(m1.w);
+            F3 norma = normalize(h.inside ? neg(T.n) : T.n);                                   // primitives.cpp:81-83,31
+            F3 x = o + h.t * d;                                                                 // scene.cpp:60
+            Frame6 &f = frames[fp];
+            if (kind == RT_MAT_DIFFUSE) {
+                F3 xo = x + epsf * norma;
+                int comp = (int)(rng_u01(rng) * (float)S.n_components);                         // distributions.h:284
+                F3 nd;
+                if (comp == 0) nd = cosine_sample(rng, norma);
+                else {                                                                          // :199-208, :129-141
+                    int li = (int)(rng_u01(rng) * (float)S.n_lights);
+                    Tri6Regs L = load_tri6(S.lights + li);
+                    float u = rng_u01(rng);
+                    float v = rng_u01(rng);
+                    if ((double)(u + v) > 1.) { u = 1 - u; v = 1 - v; }
+                    F3 point = L.a + u * L.b + v * L.c;
+                    nd = normalize(point - xo);
+                }
+                if (dot(nd, norma) < 0) { ret = emission; evaluating = false; continue; }       // scene.cpp:64-66
+                float pdf = 0.f;
+                pdf += smax(0.f, dot(nd, norma) / RT_PI_F);                                     // distributions.h:55-58
+                if (S.n_components == 2) pdf += light_pdf_sum6(S, xo, nd, stack) / (float)S.n_lights;
+                pdf = pdf / (float)S.n_components;
+                float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)dot(nd, norma));       // scene.cpp:69
+                f.kind = F6_MUL; f.emission = emission; f.mult = k * color;
+                fp++;
+                o = x + epsf * nd; d = nd;                                                      // scene.cpp:68
+            } else {
+                F3 dn = normalize(d);
+                F3 refl = dn - (float)(2. * (double)dot(norma, dn)) * norma;                    // scene.cpp:71,75
+                f.emission = emission; f.mult = color; f.x = x; f.dn = dn; f.norma = norma; f.inside = h.inside; f.ior = m0.w;
+                f.kind = kind == RT_MAT_METALLIC ? F6_MUL : F6_DIEL_REFLECT;
+                fp++;
+                o = x + epsf * refl; d = refl;                                                  // scene.cpp:72,76
+            }
+        } else {
+            if (fp == 0) break;
+            Frame6 &f = frames[--fp];
+            if (f.kind == F6_MUL) { ret = f.emission + f.mult * ret; continue; }                // scene.cpp:69,73
+            if (f.kind == F6_DIEL_REFRACT) {                                                    // scene.cpp:99-103
+                F3 refracted = ret;
+                if (!f.inside) refracted = refracted * f.mult;
+                ret = f.emission + refracted;
+                continue;
+            }
+            // F6_DIEL_REFLECT: `ret` is reflectedColor (scene.cpp:77-98)
+            float eta1 = 1.f, eta2 = f.ior;
+            if (f.inside) { float tmp = eta1; eta1 = eta2; eta2 = tmp; }
+            F3 l = neg(f.dn);
+            float nl = dot(f.norma, l);
+            float sinTheta2 = (float)((double)(eta1 / eta2) * sqrt((double)(1 - nl * nl)));
+            if (fabs((double)sinTheta2) > 1.) { ret = f.emission + ret; continue; }
+            float rr = (eta1 - eta2) / (eta1 + eta2);
+            float r0 = rr * rr;                                                                  // pow(., 2.) == exact square
+            double om = (double)(1 - nl), om2 = om * om;
+            float r = (float)((double)r0 + (double)(1 - r0) * (om2 * om2 * om));                 // pow(., 5.)
+            if (rng_u01(rng) < r) { ret = f.emission + ret; continue; }
+            float cosTheta2 = sqrtf(1 - sinTheta2 * sinTheta2);
+            F3 refr = (eta1 / eta2) * neg(l) + (eta1 / eta2 * nl - cosTheta2) * f.norma;
+            f.kind = F6_DIEL_REFRACT;
+            fp++;
+            o = f.x + epsf * refr; d = refr;
+            evaluating = true;
+            continue;
+        }
+    }
+    return ret;
+}
+
+__global__ __launch_bounds__(64) void render_hw6_kernel(SceneView6 S, RenderView R, uint32_t n_work) {
+    uint32_t stack[RT6_STACK_SIZE];
+    const int lane = threadIdx.x & 63;
+    const int sub_x = R.tile_w >> 3, sub_per_tile = sub_x * (R.tile_h >> 3);
+    for (;;) {
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(R.work_counter, 1u);
+        w = __shfl(w, 0);
+        if (w >= n_work) break;
+        uint32_t st = w / sub_per_tile, sub = w % sub_per_tile;
+        uint32_t gt = R.shard_count > 1 ? (uint32_t)R.shard_index + st * (uint32_t)R.shard_count : st;
+        int tx0 = (int)(gt % (uint32_t)R.tiles_x) * R.tile_w, ty0 = (int)(gt / (uint32_t)R.tiles_x) * R.tile_h;
+        int lx = (int)(sub % sub_x) * 8 + (lane & 7), ly = (int)(sub / sub_x) * 8 + (lane >> 3);
+        int x = tx0 + lx, y = ty0 + ly;
+        bool inside = x < R.width && y < R.height;
+        size_t out_index = R.shard_count > 1 ? ((size_t)st * R.tile_h + ly) * R.tile_w + lx : (size_t)y * R.width + x;
+        F3 px = f3(0.f, 0.f, 0.f);
+        if (inside) {
+            Rng rng;
+            rng_seed(rng, (uint32_t)(y * R.width + x));                                          // hw6/src/sceneio.cpp:281-284
+            F3 color = f3(0.f, 0.f, 0.f);
+            for (int s = 0; s < R.samples; s++) {                                                // scene.cpp:111-115
+                float nx = (float)x + rng_u01(rng);
+                float ny = (float)y + rng_u01(rng);
+                float cx = R.tan_fov_x * (2 * nx / (float)R.width - 1);                          // scene.cpp:123-126 (not normalised)
+                float cy = S.tan_fov_y * (2 * ny / (float)R.height - 1);
+                F3 dir = cx * f3(S.cam_right) - cy * f3(S.cam_up) + f3(S.cam_fwd);
+                color = color + trace_tree6(S, R.ray_depth, rng, f3(S.cam_pos), dir, stack);
+            }
+            px = R.inv_samples * color;
+        }
+        if (inside || R.shard_count > 1) {
+            if (R.out_rgb) { R.out_rgb[3 * out_index] = px.x; R.out_rgb[3 * out_index + 1] = px.y; R.out_rgb[3 * out_index + 2] = px.z; }
+            if (R.out_rgb8) {
+                R.out_rgb8[3 * out_index] = inside ? tonemap1(px.x) : 0;
+                R.out_rgb8[3 * out_index + 1] = inside ? tonemap1(px.y) : 0;
+                R.out_rgb8[3 * out_index + 2] = inside ? tonemap1(px.z) : 0;
+            }
+        }
+    }
+}
+
+} // namespace dev
+} // namespace rtamd

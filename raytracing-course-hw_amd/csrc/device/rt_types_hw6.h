@@ -1,0 +1,36 @@
+// POD layouts of the hw6 path shared by host preparation and kernels.
+#pragma once
+#include <stdint.h>
+#include "rt_types.h"
+
+namespace rtamd {
+
+// 64-byte figure record for the hw6 triangle test (hw6/src/primitives.cpp:143-164).
+struct Tri6 {
+    float a[3], b[3], c[3], n[3]; // a = data3, b = data - a, c = data2 - a, n = b.cross(c)
+    uint32_t ref_index;           // position in the reference's figure order (tie rule) / light index
+    uint32_t last;                // 1 = last record of its leaf
+    uint32_t material;
+    float point_prob;             // lights: 1 / area (hw6/src/include/distributions.h:121-127)
+};
+static_assert(sizeof(Tri6) == 64, "Tri6 must be 64 bytes");
+
+struct GpuMaterial6 {
+    float color[3]; float ior;
+    float emission[3]; int32_t kind; // rt_material_kind
+};
+static_assert(sizeof(GpuMaterial6) == 32, "GpuMaterial6 must be 32 bytes");
+
+struct SceneView6 {
+    const GpuNode *nodes;        // own SAH tree over the figures
+    const Tri6 *tris;            // in that tree's leaf order
+    const GpuNode *light_nodes;  // reference topology over the light list
+    const Tri6 *lights;          // in the reference's light order
+    const GpuMaterial6 *materials;
+    uint32_t n_tris, n_lights, n_components;
+    float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
+    float bg[3];
+    float tan_fov_y;
+};
+
+} // namespace rtamd

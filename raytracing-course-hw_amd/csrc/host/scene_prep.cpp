@@ -319,4 +319,81 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     for (int b = 0; b < 256; b++) out.srgb_lut[b] = std::pow((float)(1. / 255) * (1.f * (float)b), 2.2f);
 }
 
+
+void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out) {
+    const uint32_t n = d.n_triangles;
+    if (n >= 0x7FFFFFFFu) throw std::runtime_error("too many triangles (limit 2^31-2)");
+    if (n && (!d.positions || !d.material_index)) throw std::runtime_error("scene has triangles but no positions/material_index");
+    for (uint32_t i = 0; i < n; i++)
+        if (d.material_index[i] >= d.n_materials) throw std::runtime_error("triangle material index out of range");
+    std::vector<float> zero_keys[3], keys[3];
+    std::vector<Box3> boxes(n);
+    for (int k = 0; k < 3; k++) { zero_keys[k].assign(n, 0.f); keys[k].resize(n); }
+    for (uint32_t i = 0; i < n; i++) {
+        const float *p = d.positions + 9 * (size_t)i;
+        for (int k = 0; k < 3; k++) {
+            keys[k][i] = p[6 + k];
+            boxes[i].lo[k] = smin(p[6 + k], smin(p[k], p[3 + k])); // hw6/src/primitives.cpp:173-183
+            boxes[i].hi[k] = smax(p[6 + k], smax(p[k], p[3 + k]));
+        }
+    }
+    // 1. the reference's figure order: hw6's BVH sorts on Figure::position == (0,0,0) for every triangle
+    //    (hw6/src/include/bvh.h:61-63); the resulting permutation is what introsort does with all-equal keys.
+    out.figure_order.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.figure_order[i] = i;
+    {
+        RefBuilder ref(zero_keys, boxes, out.figure_order);
+        ref.run(n);
+        out.ref_bvh_depth = ref.depth;
+    }
+    std::vector<uint32_t> ref_pos(n);
+    for (uint32_t i = 0; i < n; i++) ref_pos[out.figure_order[i]] = i;
+    // 2. light order + light tree (reference topology: it fixes the order of the float additions)
+    auto emissive = [&](uint32_t tri) {
+        const rt_material &m = d.materials[d.material_index[tri]];
+        return !(m.emission[0] == 0 && m.emission[1] == 0 && m.emission[2] == 0);
+    };
+    std::vector<uint32_t> lorder = out.figure_order;
+    uint32_t n_lights = (uint32_t)(std::partition(lorder.begin(), lorder.end(), emissive) - lorder.begin());
+    RefBuilder light_builder(zero_keys, boxes, lorder);
+    light_builder.run(n_lights);
+    out.light_bvh_depth = light_builder.depth;
+    std::vector<uint32_t> light_leaf_last, scene_leaf_last;
+    encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
+    // 3. own scene tree: the same full-sweep SAH builder keyed on the data3 vertex (as hw8 does)
+    std::vector<uint32_t> my_order(n);
+    for (uint32_t i = 0; i < n; i++) my_order[i] = i;
+    RefBuilder mine(keys, boxes, my_order);
+    mine.run(n);
+    out.bvh_depth = mine.depth;
+    encode_tree(mine.nodes, out.nodes, scene_leaf_last);
+    auto make = [&](uint32_t src) {
+        const float *p = d.positions + 9 * (size_t)src;
+        Tri6 t;
+        memset(&t, 0, sizeof t);
+        V3 a{p[6], p[7], p[8]}, b = sub(V3{p[0], p[1], p[2]}, a), c = sub(V3{p[3], p[4], p[5]}, a);
+        V3 nn = crossr(b, c);
+        t.a[0] = a.x; t.a[1] = a.y; t.a[2] = a.z; t.b[0] = b.x; t.b[1] = b.y; t.b[2] = b.z;
+        t.c[0] = c.x; t.c[1] = c.y; t.c[2] = c.z; t.n[0] = nn.x; t.n[1] = nn.y; t.n[2] = nn.z;
+        t.material = d.material_index[src];
+        float nl = (float)std::sqrt((double)(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z));
+        t.point_prob = (float)(1.0 / (0.5 * (double)nl)); // hw6/src/include/distributions.h:126
+        return t;
+    };
+    out.tris.resize(n);
+    for (uint32_t i = 0; i < n; i++) { out.tris[i] = make(my_order[i]); out.tris[i].ref_index = ref_pos[my_order[i]]; }
+    for (uint32_t i : scene_leaf_last) out.tris[i].last = 1;
+    out.lights.resize(n_lights);
+    for (uint32_t i = 0; i < n_lights; i++) { out.lights[i] = make(out.light_order[i]); out.lights[i].ref_index = i; }
+    for (uint32_t i : light_leaf_last) out.lights[i].last = 1;
+    out.materials.resize(d.n_materials);
+    for (uint32_t i = 0; i < d.n_materials; i++) {
+        const rt_material &m = d.materials[i];
+        GpuMaterial6 &g = out.materials[i];
+        for (int k = 0; k < 3; k++) { g.color[k] = m.base_color[k]; g.emission[k] = m.emission[k]; }
+        g.ior = m.ior; g.kind = m.kind;
+    }
+}
+
 } // namespace rtamd

@@ -1,6 +1,7 @@
 #pragma once
 #include "../../../include/rtamd.h"
 #include "../device/rt_types.h"
+#include "../device/rt_types_hw6.h"
 #include <cstdint>
 #include <vector>
 
@@ -23,5 +24,15 @@ struct PreparedScene {
 
 // Throws std::runtime_error on invalid input.
 void prepare_scene(const rt_scene_desc &desc, PreparedScene &out);
+
+// hw6 flavour (flat-shaded triangles, hw6/src/scene.cpp): own scene tree + reference-topology light tree.
+struct PreparedScene6 {
+    std::vector<GpuNode> nodes, light_nodes;
+    std::vector<Tri6> tris, lights;
+    std::vector<GpuMaterial6> materials;
+    std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index
+    uint32_t bvh_depth = 0, light_bvh_depth = 0, ref_bvh_depth = 0;
+};
+void prepare_scene_hw6(const rt_scene_desc &desc, PreparedScene6 &out);
 
 } // namespace rtamd

@@ -16,6 +16,7 @@
 #include "host/scene_prep.h"
 #include "device/rt_kernels_hw8.h"
 #include "device/rt_wavefront.h"
+#include "device/rt_kernels_hw6.h"
 #include <cstdlib>
 
 namespace rtamd {
@@ -64,6 +65,8 @@ int fail(int code, const std::string &msg) {
 struct rt_scene {
     int device = 0;
     SceneView view{};
+    SceneView6 view6{};
+    int flavor = RT_INTEGRATOR_HW8; // which integrator this scene was prepared for
     std::vector<void *> allocations;
     rt_scene_info info{};
     std::vector<uint32_t> light_order;
@@ -108,6 +111,49 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         HIP_CHECK(hipGetDeviceProperties(&prop, s->device));
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         double t0 = now_ms();
+        // A scene without per-vertex normals can only be an hw6 scene (flat shading, hw6/src/sceneio.cpp:186-225).
+        if (desc->n_triangles && !desc->normals) {
+            PreparedScene6 P6;
+            prepare_scene_hw6(*desc, P6);
+            double t1 = now_ms();
+            if (P6.bvh_depth > RT6_STACK_SIZE - 2 || P6.light_bvh_depth > RT6_STACK_SIZE - 2)
+                return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P6.bvh_depth) + "/" +
+                                              std::to_string(P6.light_bvh_depth) + ")");
+            uint64_t bytes = 0;
+            SceneView6 &V = s->view6;
+            auto keep = [&](auto *p) { s->allocations.push_back((void *)p); return p; };
+            V.nodes = keep(upload(P6.nodes, bytes));
+            V.tris = keep(upload(P6.tris, bytes));
+            V.light_nodes = keep(upload(P6.light_nodes, bytes));
+            V.lights = keep(upload(P6.lights, bytes));
+            V.materials = keep(upload(P6.materials, bytes));
+            V.n_tris = desc->n_triangles;
+            V.n_lights = (uint32_t)P6.lights.size();
+            V.n_components = P6.lights.empty() ? 1u : 2u; // hw6/src/scene.cpp:8-16
+            for (int k = 0; k < 3; k++) {
+                V.cam_pos[k] = desc->camera.position[k]; V.cam_right[k] = desc->camera.right[k];
+                V.cam_up[k] = desc->camera.up[k]; V.cam_fwd[k] = desc->camera.forward[k];
+                V.bg[k] = desc->bg_color[k];
+            }
+            V.tan_fov_y = (float)std::tan((double)(desc->camera.fov_y / 2));
+            s->view.tan_fov_y = V.tan_fov_y;
+            s->flavor = RT_INTEGRATOR_HW6;
+            HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
+            s->allocations.push_back(s->d_work_counter);
+            HIP_CHECK(hipMalloc((void **)&s->d_counters, 64));
+            s->allocations.push_back(s->d_counters);
+            HIP_CHECK(hipEventCreate(&s->ev_start));
+            HIP_CHECK(hipEventCreate(&s->ev_stop));
+            HIP_CHECK(hipDeviceSynchronize());
+            double t2 = now_ms();
+            s->light_order = P6.light_order;
+            s->info.n_triangles = desc->n_triangles; s->info.n_lights = V.n_lights;
+            s->info.n_bvh_nodes = (uint32_t)P6.nodes.size(); s->info.n_light_bvh_nodes = (uint32_t)P6.light_nodes.size();
+            s->info.bvh_depth = P6.bvh_depth; s->info.light_bvh_depth = P6.light_bvh_depth;
+            s->info.device_bytes = bytes; s->info.prep_ms = t1 - t0; s->info.upload_ms = t2 - t1;
+            *out = s.release();
+            return RT_OK;
+        }
         PreparedScene P;
         prepare_scene(*desc, P);
         double t1 = now_ms();
@@ -250,7 +296,11 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
 int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
-    if (p->integrator != RT_INTEGRATOR_HW8) return fail(RT_ERR_UNSUPPORTED, "rt_render: only RT_INTEGRATOR_HW8 is implemented in this build");
+    if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render: integrator not implemented in this build");
+    if (p->integrator != scene->flavor)
+        return fail(RT_ERR_INVALID_ARG, "rt_render: this scene was prepared for integrator " + std::to_string(scene->flavor) +
+                                            " (hw6 scenes carry no vertex normals, hw8 scenes do)");
     RenderView R{};
     std::string err;
     if (!resolve_tiles(p, R, err)) return fail(RT_ERR_INVALID_ARG, "rt_render: " + err);
@@ -288,12 +338,18 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         const char *ksel = getenv("RTAMD_KERNEL");
         bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
         if (scene->info.bvh_depth > WF_STACK || scene->info.light_bvh_depth > WF_STACK || scene->info.n_triangles >= 0x40000000u) use_wavefront = false;
+        if (scene->flavor == RT_INTEGRATOR_HW6) use_wavefront = false;
+        if (scene->flavor == RT_INTEGRATOR_HW6 && R.ray_depth > RT6_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw6 ray_depth above 8");
         uint32_t launches = 0;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
             if (use_wavefront) {
                 launch_wavefront(scene, R, n_work, stream, count);
                 launches = 1 + 4 * (uint32_t)R.samples * (uint32_t)R.ray_depth;
+            } else if (scene->flavor == RT_INTEGRATOR_HW6) {
+                hipLaunchKernelGGL(dev::render_hw6_kernel, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
+                HIP_CHECK(hipGetLastError());
+                launches = 1;
             } else {
                 if (count) hipLaunchKernelGGL(dev::render_hw8_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
                 else hipLaunchKernelGGL(dev::render_hw8_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);

@@ -1,0 +1,263 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).
+//
+// CPU restatement of the two .txt-scene snapshots named by BASELINE.json:
+//   hw1  ray caster            (hw1/src/scene.cpp:7-30, hw1/src/primitives.cpp:24-91)          — configs[0]
+//   hw3  first path tracer     (hw3/src/scene.cpp:11-107, hw3/src/primitives.cpp:8-123)        — configs[1]
+// hw3 draws every random number of the whole frame from ONE file-static minstd_rand in pixel order
+// (hw3/src/scene.cpp:5-7), so the reference image can only be replayed sequentially; `seed_mode` 0 does
+// exactly that (pinned byte-for-byte against the compiled hw3 program), `seed_mode` 1 seeds one engine per
+// pixel with y*W+x like hw5+ do — the only form a parallel machine can run, used to check the GPU.
+#include "oracle_common.h"
+#include <omp.h>
+
+namespace rtot {
+using namespace rto;
+
+struct Prim {
+    int type; V3 data, position; Quat rotation; V3 color, emission; int kind; float ior;
+};
+struct Hit { float t; V3 norma; bool inside; };
+
+typedef std::uniform_real_distribution<float> U01;
+typedef std::normal_distribution<float> N01;
+
+// hw3/src/primitives.cpp:28-47 (hw1: :33-52 without the inside flag)
+static bool smallest_root(float a, float b, float c, float &t, bool &inside) {
+    float d = b * b - 4 * a * c;
+    if (d <= 0) return false;
+    float x1 = (-b - std::sqrt((double)d)) / (2 * a);
+    float x2 = (-b + std::sqrt((double)d)) / (2 * a);
+    if (x1 > x2) std::swap(x1, x2);
+    if (x2 < 0) return false;
+    if (x1 < 0) { t = x2; inside = true; } else { t = x1; inside = false; }
+    return true;
+}
+// hw3/src/primitives.cpp:81-123
+static bool box_local(V3 s, V3 o, V3 d, Hit &h) {
+    V3 ts1 = (neg1(s) - o) / d, ts2 = (s - o) / d;
+    float t1x = smin(ts1.x, ts2.x), t2x = smax(ts1.x, ts2.x);
+    float t1y = smin(ts1.y, ts2.y), t2y = smax(ts1.y, ts2.y);
+    float t1z = smin(ts1.z, ts2.z), t2z = smax(ts1.z, ts2.z);
+    float t1 = smax(smax(t1x, t1y), t1z), t2 = smin(smin(t2x, t2y), t2z);
+    if (t1 > t2 || t2 < 0) return false;
+    float t; bool inside;
+    if (t1 < 0) { inside = true; t = t2; } else { inside = false; t = t1; }
+    V3 p = o + t * d;
+    V3 n = p / s;
+    float mx = smax(smax((float)std::fabs((double)n.x), (float)std::fabs((double)n.y)), (float)std::fabs((double)n.z));
+    if (std::fabs((double)n.x) != mx) n.x = 0;
+    if (std::fabs((double)n.y) != mx) n.y = 0;
+    if (std::fabs((double)n.z) != mx) n.z = 0;
+    if (inside) n = neg1(n);
+    h = Hit{t, n, inside};
+    return true;
+}
+// hw3/src/primitives.cpp:8-26
+static bool prim_ray3(const Prim &f, V3 o, V3 d, Hit &h) {
+    V3 to = qtransform(f.rotation, o - f.position), td = qtransform(f.rotation, d);
+    bool ok;
+    if (f.type == RT_PRIM_ELLIPSOID) {                                     // :49-67
+        V3 r = f.data;
+        float c = len2(to / r) - 1;
+        float b = 2. * dot(to / r, td / r);
+        float a = len2(td / r);
+        float t; bool inside;
+        ok = smallest_root(a, b, c, t, inside);
+        if (ok) {
+            V3 point = to + t * td;
+            V3 n = point / (r * r);
+            if (inside) n = neg1(n);
+            h = Hit{t, normalize(n), inside};
+        }
+    } else if (f.type == RT_PRIM_PLANE) {                                   // :69-79 (no T_MAX in hw3)
+        V3 n = f.data;
+        float t = -dot(to, n) / dot(td, n);
+        ok = t > 0;
+        if (ok) h = dot(td, n) > 0 ? Hit{t, neg1(n), true} : Hit{t, n, false};
+    } else ok = box_local(f.data, to, td, h);
+    if (!ok) return false;
+    h.norma = normalize(qtransform(qconj(f.rotation), h.norma));
+    return true;
+}
+
+struct Scene3 {
+    std::vector<Prim> figs;
+    V3 camPos, camRight, camUp, camFwd, bg;
+    float fovX = 0;
+    int width = 0, height = 0, samples = 1, rayDepth = 1;
+
+    // hw3/src/scene.cpp:11-29 (tmax = +inf)
+    bool intersect(V3 o, V3 d, Hit &best, int &pos) const {
+        pos = -1;
+        for (int i = 0; i < (int)figs.size(); i++) {
+            Hit h;
+            if (prim_ray3(figs[i], o, d, h) && h.t <= INFINITY && (pos == -1 || h.t < best.t)) { best = h; pos = i; }
+        }
+        return pos != -1;
+    }
+    // hw3/src/scene.cpp:31-87
+    V3 get_color(rng_t &rnd, U01 &u01, N01 &n01, V3 ro, V3 rd, int recLimit) const {
+        if (recLimit == 0) return V3{0., 0., 0.};
+        Hit h; int pos;
+        if (!intersect(ro, rd, h, pos)) return bg;
+        const Prim &f = figs[pos];
+        float t = h.t; V3 norma = h.norma;
+        if (f.kind == RT_MAT_DIFFUSE) {
+            float a = n01(rnd), b = n01(rnd), c = n01(rnd);
+            V3 w = normalize(V3{a, b, c});
+            if (dot(w, norma) < 0) w = neg1(w);
+            V3 o = ro + t * rd + (float)0.0001 * w;
+            return f.emission + (2 * dot(w, norma)) * f.color * get_color(rnd, u01, n01, o, w, recLimit - 1);
+        } else if (f.kind == RT_MAT_METALLIC) {
+            V3 dn = normalize(rd);
+            V3 refl = dn - (float)(2. * dot(norma, dn)) * norma;
+            V3 o = ro + t * rd + (float)0.0001 * refl;
+            return f.emission + f.color * get_color(rnd, u01, n01, o, refl, recLimit - 1);
+        } else {
+            V3 dn = normalize(rd);
+            V3 refl = dn - (float)(2. * dot(norma, dn)) * norma;
+            V3 o = ro + t * rd + (float)0.0001 * refl;
+            V3 reflected = get_color(rnd, u01, n01, o, refl, recLimit - 1);
+            float eta1 = 1., eta2 = f.ior;
+            if (h.inside) std::swap(eta1, eta2);
+            V3 l = neg1(normalize(rd));
+            float sinTheta2 = eta1 / eta2 * std::sqrt((double)(1 - dot(norma, l) * dot(norma, l)));
+            if (std::fabs((double)sinTheta2) > 1.) return f.emission + reflected;
+            float r0 = std::pow((double)((eta1 - eta2) / (eta1 + eta2)), 2.);
+            float r = r0 + (1 - r0) * std::pow((double)(1 - dot(norma, l)), 5.);
+            if (u01(rnd) < r) return f.emission + reflected;
+            float cosTheta2 = std::sqrt((double)(1 - sinTheta2 * sinTheta2));
+            V3 refr = (eta1 / eta2) * neg1(l) + (eta1 / eta2 * dot(norma, l) - cosTheta2) * norma;
+            V3 fo = ro + t * rd + (float)0.0001 * refr;
+            V3 refracted = get_color(rnd, u01, n01, fo, refr, recLimit - 1);
+            if (!h.inside) refracted = refracted * f.color;
+            return f.emission + refracted;
+        }
+    }
+    // hw3/src/scene.cpp:99-107
+    void camera_ray(float x, float y, V3 &o, V3 &d) const {
+        float tanFovX = std::tan((double)(fovX / 2));
+        float tanFovY = tanFovX * height / width;
+        float nx = tanFovX * (2 * (x + 0.5) / width - 1);
+        float ny = tanFovY * (2 * (y + 0.5) / height - 1);
+        o = camPos;
+        d = nx * camRight - ny * camUp + camFwd;
+    }
+    // hw3/src/scene.cpp:89-97
+    V3 get_pixel(rng_t &rnd, U01 &u01, N01 &n01, int x, int y) const {
+        V3 color{0, 0, 0};
+        for (int s = 0; s < samples; s++) {
+            float nx = x + u01(rnd);
+            float ny = y + u01(rnd);
+            V3 o, d;
+            camera_ray(nx, ny, o, d);
+            color = color + get_color(rnd, u01, n01, o, d, rayDepth);
+        }
+        return (float)(1.0 / samples) * color;
+    }
+};
+
+// ---- hw1 -------------------------------------------------------------------------------------------------
+// hw1/src/primitives.cpp:24-91: nearest primitive, flat colour, no normals.
+static bool prim_ray1(const Prim &f, V3 o, V3 d, float &t) {
+    V3 to = qtransform(f.rotation, o - f.position), td = qtransform(f.rotation, d);
+    if (f.type == RT_PRIM_ELLIPSOID) {                                     // :54-59: b = (2*(o/r)) . (d/r)
+        V3 r = f.data;
+        float c = len2(to / r) - 1;
+        float b = dot(2 * (to / r), td / r);
+        float a = len2(td / r);
+        float dd = b * b - 4 * a * c;
+        if (dd <= 0) return false;
+        float x1 = (-b - std::sqrt((double)dd)) / (2 * a);
+        float x2 = (-b + std::sqrt((double)dd)) / (2 * a);
+        if (x1 > x2) std::swap(x1, x2);
+        if (x2 < 0) return false;
+        t = x1 < 0 ? x2 : x1;
+        return true;
+    }
+    if (f.type == RT_PRIM_PLANE) {                                          // :64-70
+        t = -dot(to, f.data) / dot(td, f.data);
+        return t > 0;
+    }
+    V3 s = f.data;                                                          // :76-91
+    V3 ts1 = (neg1(s) - to) / td, ts2 = (s - to) / td;
+    float t1x = smin(ts1.x, ts2.x), t2x = smax(ts1.x, ts2.x);
+    float t1y = smin(ts1.y, ts2.y), t2y = smax(ts1.y, ts2.y);
+    float t1z = smin(ts1.z, ts2.z), t2z = smax(ts1.z, ts2.z);
+    float t1 = smax(smax(t1x, t1y), t1z), t2 = smin(smin(t2x, t2y), t2z);
+    if (t1 > t2 || t2 < 0) return false;
+    t = t1 < 0 ? t2 : t1;
+    return true;
+}
+
+static V3 v3(const float *p) { return {p[0], p[1], p[2]}; }
+static Scene3 *make_scene(const rt_scene_desc *d) {
+    Scene3 *s = new Scene3();
+    for (uint32_t i = 0; i < d->n_primitives; i++) {
+        const rt_primitive &p = d->primitives[i];
+        Prim f;
+        f.type = p.type; f.data = v3(p.data); f.position = v3(p.position);
+        f.rotation = Quat{v3(p.rotation), p.rotation[3]};
+        f.color = v3(p.color); f.emission = v3(p.emission); f.kind = p.kind; f.ior = p.ior;
+        s->figs.push_back(f);
+    }
+    s->camPos = v3(d->camera.position); s->camRight = v3(d->camera.right); s->camUp = v3(d->camera.up); s->camFwd = v3(d->camera.forward);
+    s->fovX = d->camera.fov_x; s->bg = v3(d->bg_color);
+    return s;
+}
+} // namespace rtot
+
+using namespace rtot;
+extern "C" {
+void *rto_txt_create(const rt_scene_desc *d) { return make_scene(d); }
+void rto_txt_destroy(void *p) { delete (Scene3 *)p; }
+
+// hw1: out8 = round(255*colour) bytes (hw1/src/color.cpp:13-19), out_rgb = the colour itself.
+int rto_hw1_render(void *p, int width, int height, float *out_rgb, uint8_t *out8) {
+    Scene3 *s = (Scene3 *)p;
+    s->width = width; s->height = height;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            V3 o, d;
+            s->camera_ray((float)x, (float)y, o, d); // hw1/src/scene.cpp:22-30 takes ints; (x + 0.5) is the same double either way
+            V3 ans = s->bg;
+            float best = -1;
+            for (const Prim &f : s->figs) {
+                float t;
+                if (prim_ray1(f, o, d, t) && (best == -1 || t < best)) { best = t; ans = f.color; }
+            }
+            size_t j = (size_t)y * width + x;
+            if (out_rgb) { out_rgb[3 * j] = ans.x; out_rgb[3 * j + 1] = ans.y; out_rgb[3 * j + 2] = ans.z; }
+            if (out8) { out8[3 * j] = (uint8_t)std::round((double)(255 * ans.x)); out8[3 * j + 1] = (uint8_t)std::round((double)(255 * ans.y)); out8[3 * j + 2] = (uint8_t)std::round((double)(255 * ans.z)); }
+        }
+    return 0;
+}
+
+// hw3.  seed_mode 0: one engine for the whole frame, pixels in row-major order (the reference, single thread);
+//       seed_mode 1: engine(y*W+x) per pixel (parallel).
+int rto_hw3_render(void *p, int width, int height, int samples, int ray_depth, int seed_mode, int x0, int y0, int w, int h,
+                   float *out_rgb, uint8_t *out8, int nthreads) {
+    Scene3 *s = (Scene3 *)p;
+    s->width = width; s->height = height; s->samples = samples; s->rayDepth = ray_depth;
+    if (seed_mode == 0) {
+        rng_t rnd; U01 u01(0.0, 1.0); N01 n01(0.0, 1.0);   // hw3/src/scene.cpp:5-7: default-seeded, shared by everything
+        for (int j = 0; j < w * h; j++) {
+            int x = x0 + j % w, y = y0 + j / w;
+            V3 px = s->get_pixel(rnd, u01, n01, x, y);
+            if (out_rgb) { out_rgb[3 * j] = px.x; out_rgb[3 * j + 1] = px.y; out_rgb[3 * j + 2] = px.z; }
+            if (out8) to_extern(gamma_corrected(aces_tonemap(px)), out8 + 3 * j);
+        }
+        return 0;
+    }
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads)
+    for (int j = 0; j < w * h; j++) {
+        int x = x0 + j % w, y = y0 + j / w;
+        rng_t rnd(y * width + x); U01 u01(0.0, 1.0); N01 n01(0.0, 1.0);
+        V3 px = s->get_pixel(rnd, u01, n01, x, y);
+        if (out_rgb) { out_rgb[3 * j] = px.x; out_rgb[3 * j + 1] = px.y; out_rgb[3 * j + 2] = px.z; }
+        if (out8) to_extern(gamma_corrected(aces_tonemap(px)), out8 + 3 * j);
+    }
+    return 0;
+}
+}

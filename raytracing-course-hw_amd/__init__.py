@@ -128,7 +128,7 @@ class SceneData:
     def __init__(self, positions, texcoords, normals, tangents, material_index, materials, texture_source=(), images=(),
                  camera=None, bg=(0, 0, 0), environment=None, primitives=None):
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
-        self.positions = f32(positions).reshape(-1, 9)
+        self.positions = f32(positions if positions is not None else np.zeros(0, np.float32)).reshape(-1, 9)
         n = self.positions.shape[0]
         self.texcoords = None if texcoords is None else f32(texcoords).reshape(n, 6)
         self.normals = None if normals is None else f32(normals).reshape(n, 9)
@@ -203,6 +203,17 @@ def load_gltf(path, flavor=RT_INTEGRATOR_HW8, environment=None):
         if environment is not None:
             _check(lib.rt_host_scene_set_environment(hs, os.fsencode(environment)))
         return SceneData.from_desc(lib.rt_host_scene_desc(hs).contents)
+    finally:
+        lib.rt_host_scene_free(hs)
+
+
+def load_txt(path, flavor=RT_INTEGRATOR_HW3):
+    """Load a .txt scene (hw1/hw3 grammar). Returns (SceneData, width, height, samples, ray_depth)."""
+    hs = C.c_void_p()
+    w, h, s, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib.rt_load_txt(os.fsencode(path), flavor, C.byref(hs), C.byref(w), C.byref(h), C.byref(s), C.byref(d)))
+    try:
+        return SceneData.from_desc(lib.rt_host_scene_desc(hs).contents), w.value, h.value, s.value, d.value
     finally:
         lib.rt_host_scene_free(hs)
 

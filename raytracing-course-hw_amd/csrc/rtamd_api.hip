@@ -17,6 +17,7 @@
 #include "device/rt_kernels_hw8.h"
 #include "device/rt_wavefront.h"
 #include "device/rt_kernels_hw6.h"
+#include "device/rt_kernels_txt.h"
 #include <cstdlib>
 
 namespace rtamd {
@@ -66,6 +67,7 @@ struct rt_scene {
     int device = 0;
     SceneView view{};
     SceneView6 view6{};
+    SceneViewTxt viewt{};
     int flavor = RT_INTEGRATOR_HW8; // which integrator this scene was prepared for
     std::vector<void *> allocations;
     rt_scene_info info{};
@@ -111,6 +113,42 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         HIP_CHECK(hipGetDeviceProperties(&prop, s->device));
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         double t0 = now_ms();
+        // Analytic primitives only: a .txt scene (hw1 / hw3).
+        if (desc->n_triangles == 0 && desc->n_primitives > 0) {
+            std::vector<GpuPrim> prims(desc->n_primitives);
+            for (uint32_t i = 0; i < desc->n_primitives; i++) {
+                const rt_primitive &p = desc->primitives[i];
+                GpuPrim &g = prims[i];
+                memset(&g, 0, sizeof g);
+                if (p.type < RT_PRIM_ELLIPSOID || p.type > RT_PRIM_BOX) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: bad primitive type");
+                for (int k = 0; k < 3; k++) { g.data[k] = p.data[k]; g.position[k] = p.position[k]; g.color[k] = p.color[k]; g.emission[k] = p.emission[k]; }
+                for (int k = 0; k < 4; k++) g.rotation[k] = p.rotation[k];
+                g.type = p.type; g.kind = p.kind; g.ior = p.ior;
+            }
+            uint64_t bytes = 0;
+            SceneViewTxt &V = s->viewt;
+            V.prims = upload(prims, bytes);
+            s->allocations.push_back((void *)V.prims);
+            V.n_prims = desc->n_primitives;
+            for (int k = 0; k < 3; k++) {
+                V.cam_pos[k] = desc->camera.position[k]; V.cam_right[k] = desc->camera.right[k];
+                V.cam_up[k] = desc->camera.up[k]; V.cam_fwd[k] = desc->camera.forward[k];
+                V.bg[k] = desc->bg_color[k];
+            }
+            V.tan_fov_x = (float)std::tan((double)(desc->camera.fov_x / 2)); // hw3/src/scene.cpp:100
+            s->flavor = RT_INTEGRATOR_HW3;
+            HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
+            s->allocations.push_back(s->d_work_counter);
+            HIP_CHECK(hipMalloc((void **)&s->d_counters, 64));
+            s->allocations.push_back(s->d_counters);
+            HIP_CHECK(hipEventCreate(&s->ev_start));
+            HIP_CHECK(hipEventCreate(&s->ev_stop));
+            HIP_CHECK(hipDeviceSynchronize());
+            s->info.device_bytes = bytes;
+            s->info.prep_ms = 0; s->info.upload_ms = now_ms() - t0;
+            *out = s.release();
+            return RT_OK;
+        }
         // A scene without per-vertex normals can only be an hw6 scene (flat shading, hw6/src/sceneio.cpp:186-225).
         if (desc->n_triangles && !desc->normals) {
             PreparedScene6 P6;
@@ -296,9 +334,11 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
 int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
-    if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6)
-        return fail(RT_ERR_UNSUPPORTED, "rt_render: integrator not implemented in this build");
-    if (p->integrator != scene->flavor)
+    if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6 && p->integrator != RT_INTEGRATOR_HW3 && p->integrator != RT_INTEGRATOR_HW1)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown integrator");
+    const bool txt_scene = scene->flavor == RT_INTEGRATOR_HW3;
+    const bool txt_integrator = p->integrator == RT_INTEGRATOR_HW3 || p->integrator == RT_INTEGRATOR_HW1;
+    if (txt_scene != txt_integrator || (!txt_scene && p->integrator != scene->flavor))
         return fail(RT_ERR_INVALID_ARG, "rt_render: this scene was prepared for integrator " + std::to_string(scene->flavor) +
                                             " (hw6 scenes carry no vertex normals, hw8 scenes do)");
     RenderView R{};
@@ -338,7 +378,10 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         const char *ksel = getenv("RTAMD_KERNEL");
         bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
         if (scene->info.bvh_depth > WF_STACK || scene->info.light_bvh_depth > WF_STACK || scene->info.n_triangles >= 0x40000000u) use_wavefront = false;
-        if (scene->flavor == RT_INTEGRATOR_HW6) use_wavefront = false;
+        if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
+        if (txt_scene && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
+        if (p->integrator == RT_INTEGRATOR_HW1 && R.shard_count > 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: the hw1 caster renders unsharded frames only");
+        const float txt_tan_fov_y = scene->viewt.tan_fov_x * R.height / R.width; // hw3/src/scene.cpp:101
         if (scene->flavor == RT_INTEGRATOR_HW6 && R.ray_depth > RT6_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw6 ray_depth above 8");
         uint32_t launches = 0;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
@@ -346,6 +389,15 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             if (use_wavefront) {
                 launch_wavefront(scene, R, n_work, stream, count);
                 launches = 1 + 4 * (uint32_t)R.samples * (uint32_t)R.ray_depth;
+            } else if (p->integrator == RT_INTEGRATOR_HW1) {
+                uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
+                hipLaunchKernelGGL(dev::render_hw1_kernel, dim3((npx + 255) / 256), dim3(256), 0, stream, scene->viewt, R.width, R.height, txt_tan_fov_y, d_rgb, d_rgb8);
+                HIP_CHECK(hipGetLastError());
+                launches = 1;
+            } else if (txt_scene) {
+                hipLaunchKernelGGL(dev::render_hw3_kernel, dim3(blocks), dim3(64), 0, stream, scene->viewt, R, txt_tan_fov_y, n_work);
+                HIP_CHECK(hipGetLastError());
+                launches = 1;
             } else if (scene->flavor == RT_INTEGRATOR_HW6) {
                 hipLaunchKernelGGL(dev::render_hw6_kernel, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
                 HIP_CHECK(hipGetLastError());

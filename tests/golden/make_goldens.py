@@ -44,6 +44,22 @@ def main():
         out[name + "_rgb"], out[name + "_rgb8"] = rgb, rgb8
         print(name, rgb.shape, float(rgb.mean()))
     np.savez_compressed(os.path.join(HERE, "pins_hw6_render.npz"), **out)
+    # byte-level pins through the reference's own unmodified CLI programs (hw1, hw3)
+    import hashlib
+    import subprocess
+    import tempfile
+    txt = os.path.join(HERE, "scenes", "txt")
+    out = {}
+    for name, prog in (("hw1_sample", "hw1_main"), ("hw1_sample_256", "hw1_main"), ("hw3_practice3_5_64x48x8", "hw3_main"), ("hw3_mixed_materials", "hw3_main")):
+        with tempfile.TemporaryDirectory() as td:
+            ppm = os.path.join(td, "o.ppm")
+            subprocess.run([oracle_lib.ref_path(prog), os.path.join(txt, name + ".txt"), ppm], check=True, stderr=subprocess.DEVNULL)
+            data = open(ppm, "rb").read()
+        out[name + "_md5"] = np.frombuffer(hashlib.md5(data).hexdigest().encode(), np.uint8)
+        if len(data) < 100000:
+            out[name + "_ppm"] = np.frombuffer(data, np.uint8)
+        print(name, hashlib.md5(data).hexdigest(), len(data))
+    np.savez_compressed(os.path.join(HERE, "pins_txt_programs.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ class Counters(C.Structure):
 
 def _build():
     so = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
-    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_hw8.cpp", "oracle_common.h")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_hw8.cpp", "oracle_hw6.cpp", "oracle_txt.cpp", "oracle_common.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "_build/liboracle.so"])
     return so
@@ -264,3 +264,35 @@ class Ref6:
         rgb8 = np.zeros((h, w, 3), np.uint8)
         self.L.ref6_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
         return rgb, rgb8, None
+
+
+class TxtOracle:
+    """CPU restatement of the .txt-scene snapshots hw1 and hw3 (oracle/oracle_txt.cpp)."""
+
+    def __init__(self, scene_data):
+        self.data = scene_data
+        L = lib()
+        L.rto_txt_create.restype = C.c_void_p
+        L.rto_txt_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.rto_txt_destroy.argtypes = [C.c_void_p]
+        L.rto_hw1_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.rto_hw3_render.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_void_p, C.c_int]
+        self._h = L.rto_txt_create(C.byref(scene_data.desc))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rto_txt_destroy(self._h)
+            self._h = None
+
+    def render_hw1(self, width, height):
+        rgb = np.zeros((height, width, 3), np.float32)
+        rgb8 = np.zeros((height, width, 3), np.uint8)
+        lib().rto_hw1_render(self._h, width, height, rgb.ctypes.data, rgb8.ctypes.data)
+        return rgb, rgb8
+
+    def render_hw3(self, width, height, samples, ray_depth, per_pixel_seed, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        lib().rto_hw3_render(self._h, width, height, samples, ray_depth, 1 if per_pixel_seed else 0, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
+        return rgb, rgb8

@@ -72,6 +72,30 @@ def test_hw6_whole_integrator_bit_exact(name):
     assert same(rgb8, gold[name + "_rgb8"])
 
 
+def _ppm(w, h, rgb8):
+    return b"P6\n%d %d\n255\n" % (w, h) + rgb8.tobytes()
+
+
+@pytest.mark.parametrize("name,flavor", [("hw1_sample", 1), ("hw1_sample_256", 1), ("hw3_practice3_5_64x48x8", 3), ("hw3_mixed_materials", 3)])
+def test_txt_programs_byte_identical(name, flavor):
+    """The unmodified hw1 / hw3 CLI programs of the reference vs this repo's .txt loader + oracle/oracle_txt.cpp
+    (hw3 in its sequential single-engine mode): the PPM files must be byte-identical.  hw1_sample is the md5 the
+    survey recorded (353a1038...); hw1_sample_256 is BASELINE.json configs[0]."""
+    import hashlib
+    import importlib
+    rt = importlib.import_module("raytracing-course-hw_amd")
+    gold = np.load(os.path.join(GOLD, "pins_txt_programs.npz"))
+    sd, w, h, spp, depth = rt.load_txt(os.path.join(GOLD, "scenes", "txt", name + ".txt"), flavor)
+    orc = oracle_lib.TxtOracle(sd)
+    rgb8 = orc.render_hw1(w, h)[1] if flavor == 1 else orc.render_hw3(w, h, spp, depth, per_pixel_seed=False)[1]
+    data = _ppm(w, h, rgb8)
+    assert hashlib.md5(data).hexdigest() == bytes(gold[name + "_md5"]).decode()
+    if name + "_ppm" in gold:
+        assert data == bytes(gold[name + "_ppm"])
+    if name == "hw1_sample":
+        assert hashlib.md5(data).hexdigest() == "353a1038e8aaa368d2957931be2cf87d"  # SURVEY.md §6
+
+
 def test_hw8_sphere_matches_reference_values_recorded_in_survey():
     """SURVEY.md §8(c) records three pixels of the compiled hw8 reference (sphere_emissive, 64x64, 4 spp,
     through the public Scene::getPixel).  They cover the full hw8 getColor, incl. the emissive texture."""

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--workload", default="synth_room_v1_1920x1080x256", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (profiling only: the result is not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
     args = ap.parse_args()
@@ -73,7 +74,7 @@ def main():
     import gen_synth_room
 
     wl = WORKLOADS[args.workload]
-    W, H, SPP = wl["width"], wl["height"], wl["spp"]
+    W, H, SPP = wl["width"], wl["height"], (args.spp if args.spp > 0 else wl["spp"])
     tmp = tempfile.mkdtemp(prefix=f"synth_room_r{rank}_")
     t0 = time.time()
     gltf, n_tris = gen_synth_room.generate(tmp, wl["spheres"], wl["segs"], wl["rings"])
@@ -154,7 +155,8 @@ def main():
             dt = time.perf_counter() - t1
             cpu = {"value": round(cw * ch * cspp / dt / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
                    "sample": f"oracle (CPU restatement, OpenMP dynamic,8) on the centre {cw}x{ch} pixel block of the same {W}x{H} frame at {cspp} spp, {dt:.1f} s"}
-        result = {"metric": "Msamples/sec at 1920x1080x256spp" if args.workload.endswith("1920x1080x256") else f"Msamples/sec ({args.workload})",
+        headline = args.workload.endswith("1920x1080x256") and args.spp <= 0
+        result = {"metric": "Msamples/sec at 1920x1080x256spp" if headline else f"Msamples/sec ({args.workload}, spp={SPP}; NOT the headline config)",
                   "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
                   "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -678,6 +678,8 @@ void rto_rng_kat(uint32_t seed, int n_u, int n_n, float *out) {
     for (int i = 0; i < n_u; i++) out[i] = u01(rng);
     for (int i = 0; i < n_n; i++) out[n_u + i] = n01(rng);
 }
+// Host libm logf (what the reference's normal_distribution calls) on an array.
+void rto_logf_array(const float *in, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = std::log(in[i]); }
 // Same engine, normals drawn first, then uniforms.
 void rto_rng_kat_normals_first(uint32_t seed, int n_n, int n_u, float *out) {
     rng_t rng(seed); U01 u01(0.0, 1.0); N01 n01(0.0, 1.0);

@@ -58,6 +58,25 @@ RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh,
     sh.metallic = mr.z;                                                             // :149
 }
 
+// Only the emission of a hit (scene.cpp:117-125) — all the deepest level of a path can contribute when the
+// scene allows the shortcut (SceneView::last_level_emission_only).
+RT_DEV F3 emission_fetch(const SceneView &S, const HitRec &h) {
+    const float4 *q = reinterpret_cast<const float4 *>(S.tri_shade + h.idx);
+    float4 s6 = q[6];
+    uint32_t mat = __float_as_uint(s6.y);
+    const float4 *qm = reinterpret_cast<const float4 *>(S.materials + mat);
+    float4 m1 = qm[1], m2 = qm[2];
+    F3 emission = f3(m1.x, m1.y, m1.z);
+    int tex_emis = (int)__float_as_uint(m2.y);
+    if (tex_emis >= 0) {
+        float4 s4 = q[4], s5 = q[5];
+        float tu = s4.z + h.u * s5.x + h.v * s5.z;                // primitives.cpp:111-114
+        float tv = s4.w + h.u * s5.y + h.v * s5.w;
+        emission = emission * sample_texture(S, tex_emis, tu, tv, true);
+    }
+    return emission;
+}
+
 RT_DEV F3 miss_color(const SceneView &S, F3 d) { // scene.cpp:90-97
     if (S.env_image < 0) return f3(S.bg);
     float tx = (float)(0.5 + 0.5 * atan2((double)d.z, (double)d.x) / RT_PI);

@@ -77,6 +77,10 @@ struct SceneView {
     const uint8_t *texels;
     const float *srgb_lut;         // 256 entries: powf(float(1/255.)*b, 2.2f) evaluated by the host libm
     uint32_t n_tris, n_lights, n_components;
+    // 1 when every material has 0 <= metallicFactor <= 1 and a non-negative base colour: then the BRDF is >= 0,
+    // the throughput of the deepest level is in [0, inf] or NaN, and that level returns exactly its emission
+    // (emission + mult*0, or emission via the clamp) — the wavefront path then skips its BRDF/pdf work.
+    uint32_t last_level_emission_only;
     int32_t env_image;             // image slot of the environment map or -1
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float bg[3];

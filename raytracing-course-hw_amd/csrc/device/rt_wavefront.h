@@ -16,8 +16,9 @@
 // keep their lanes busy by pulling the next ray as soon as one finishes; the two shading kernels run
 // with full waves.  Arithmetic is the same bit-exact code as the single-kernel path (rt_device.h).
 //
-// HBM layout per pixel slot: one 64-byte record (ray, hit, RNG, accumulator) + ray_depth 32-byte stack
-// entries, so a scattered access still moves whole cache lines.
+// HBM layout per pixel slot: one 64-byte record (ray, hit, RNG, accumulator) followed by ray_depth 32-byte
+// stack entries, contiguous (256 B per slot at depth 6), so a scattered access still moves whole cache
+// lines and the backward fold at the end of a path reads one contiguous run.
 #pragma once
 #include "rt_kernels_hw8.h"
 
@@ -30,13 +31,16 @@ namespace dev {
 // hit: 0xFFFFFFFF = miss, else triangle index | inside << 30.   After light(r), q2.x holds the light sum.
 // Stack entry (2 x float4): E0 = emission.xyz, pdf_partial   E1 = brdf (then mult).xyz, dot(d, n_s)
 struct WfView {
-    float4 *r0;
-    float4 *stack;          // [level][slot][2]
+    float4 *r0;             // per slot: `stride` float4 = 4 (R0 record) + 2 per stack level, contiguous
+    uint32_t stride;
     uint32_t *q_trace[2];
     uint32_t *q_light;
     uint32_t *ctr;          // per round r: ctr[4r+0] = trace count, +1 = light count, +2 = trace head, +3 = light head
     uint32_t n_slots;
 };
+
+RT_DEV float4 *wf_rec(const WfView &W, uint32_t slot) { return W.r0 + (size_t)slot * W.stride; }
+RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0 + (size_t)slot * W.stride + 4 + 2 * level; }
 
 #define WF_MISS 0xFFFFFFFFu
 #define WF_INSIDE_BIT 0x40000000u
@@ -56,16 +60,35 @@ RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y,
     out_index = R.shard_count > 1 ? ((size_t)st * R.tile_h + ly) * R.tile_w + lx : (size_t)y * R.width + x;
 }
 
-// Wave-aggregated queue append (one atomic per wave, order of the active lanes preserved).
-RT_DEV void wf_push(uint32_t *queue, uint32_t *count, uint32_t slot) {
+
+// ---- queue append, aggregated per workgroup -------------------------------------------------------------
+// One global atomic on a single address retires at ~88 per microsecond (MI355X_MICROARCH.md "dequeue"), which
+// would bound a kernel that appends once per wave.  Appends therefore go to an LDS staging buffer (LDS atomic
+// per wave) and reach the global queue with ONE atomic per ~2k items, written coalesced.
+#define WF_BUF 2048
+struct Pusher { uint32_t *buf; uint32_t *cnt; };
+RT_DEV void wf_push(const Pusher &p, uint32_t slot) {
     unsigned long long mask = __ballot(1);
     int lane = threadIdx.x & 63;
     int leader = __ffsll((long long)mask) - 1;
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    if (lane == leader) base = atomicAdd(p.cnt, (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
     uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    queue[base + rank] = slot;
+    p.buf[base + rank] = slot;
+}
+// Called by every thread of the block, after a __syncthreads() that follows the last push.
+RT_DEV void wf_flush(const Pusher &p, uint32_t *gqueue, uint32_t *gcount, uint32_t *shared_base) {
+    uint32_t n = *p.cnt;
+    if (n) {
+        if (threadIdx.x == 0) *shared_base = atomicAdd(gcount, n);
+        __syncthreads();
+        uint32_t gb = *shared_base;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gqueue[gb + i] = p.buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) *p.cnt = 0;
+    }
+    __syncthreads();
 }
 
 RT_DEV void wf_camera_ray(const SceneView &S, const RenderView &R, Rng &rng, int x, int y, F3 &o, F3 &d) {
@@ -80,10 +103,10 @@ RT_DEV void wf_camera_ray(const SceneView &S, const RenderView &R, Rng &rng, int
 // End of one camera sample: fold e + m*(inner) backwards (scene.cpp:164), add to the pixel sum
 // (scene.cpp:174), then either start the next sample or write the finished pixel.
 RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, int depth, F3 tail, F3 accum,
-                           Rng &rng, uint32_t sample, uint32_t *next_queue, uint32_t *next_count) {
+                           Rng &rng, uint32_t sample, const Pusher &next) {
     F3 L = tail;
     for (int b = depth - 1; b >= 0; b--) {
-        const float4 *e = W.stack + ((size_t)b * W.n_slots + slot) * 2;
+        const float4 *e = wf_entry(W, slot, b);
         float4 e0 = e[0], e1 = e[1];
         L = f3(e0.x, e0.y, e0.z) + f3(e1.x, e1.y, e1.z) * L;
     }
@@ -94,11 +117,11 @@ RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView
     if (sample < (uint32_t)R.samples) {
         F3 o, d;
         wf_camera_ray(S, R, rng, x, y, o, d);
-        float4 *r = W.r0 + (size_t)slot * 4;
+        float4 *r = wf_rec(W, slot);
         r[0] = make_float4(o.x, o.y, o.z, d.x);
         r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
         r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(0, rng.has_saved, sample)));
-        wf_push(next_queue, next_count, slot);
+        wf_push(next, slot);
     } else {
         F3 px = R.inv_samples * accum;                               // scene.cpp:176
         if (R.out_rgb) { R.out_rgb[3 * out_index] = px.x; R.out_rgb[3 * out_index + 1] = px.y; R.out_rgb[3 * out_index + 2] = px.z; }
@@ -110,54 +133,67 @@ RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView
 
 // ---- init: seed every pixel, first camera ray, fill the round-0 trace queue ------------------------------
 __global__ __launch_bounds__(256) void wf_init_kernel(SceneView S, RenderView R, WfView W) {
-    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (slot >= W.n_slots) return;
-    int x, y; bool inside; size_t out_index;
-    wf_slot_to_pixel(R, slot, x, y, inside, out_index);
-    if (!inside) { // padding of a border tile in the compact shard layout
-        if (R.shard_count > 1) {
-            if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
-            if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
+    __shared__ uint32_t buf[WF_BUF];
+    __shared__ uint32_t cnt, gbase;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    Pusher q; q.buf = buf; q.cnt = &cnt;
+    for (uint32_t base = blockIdx.x * 256u; base < W.n_slots; base += gridDim.x * 256u) {
+        uint32_t slot = base + threadIdx.x;
+        if (slot < W.n_slots) {
+            int x, y; bool inside; size_t out_index;
+            wf_slot_to_pixel(R, slot, x, y, inside, out_index);
+            if (!inside) { // padding of a border tile in the compact shard layout
+                if (R.shard_count > 1) {
+                    if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
+                    if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
+                }
+            } else {
+                Rng rng;
+                rng_seed(rng, (uint32_t)(y * R.width + x));          // sceneio.cpp:389-391
+                F3 o, d;
+                wf_camera_ray(S, R, rng, x, y, o, d);
+                float4 *r = wf_rec(W, slot);
+                r[0] = make_float4(o.x, o.y, o.z, d.x);
+                r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
+                r[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                r[3] = make_float4(0.f, 0.f, 0.f, __uint_as_float(wf_pack(0, rng.has_saved, 0)));
+                wf_push(q, slot);
+            }
         }
-        return;
+        __syncthreads();
+        if (cnt > WF_BUF - 256) wf_flush(q, W.q_trace[0], W.ctr + 0, &gbase);
     }
-    Rng rng;
-    rng_seed(rng, (uint32_t)(y * R.width + x));                      // sceneio.cpp:389-391
-    F3 o, d;
-    wf_camera_ray(S, R, rng, x, y, o, d);
-    float4 *r = W.r0 + (size_t)slot * 4;
-    r[0] = make_float4(o.x, o.y, o.z, d.x);
-    r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
-    r[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    r[3] = make_float4(0.f, 0.f, 0.f, __uint_as_float(wf_pack(0, rng.has_saved, 0)));
-    wf_push(W.q_trace[0], W.ctr + 0, slot);
+    __syncthreads();
+    wf_flush(q, W.q_trace[0], W.ctr + 0, &gbase);
 }
 
-// ---- traversal kernels: persistent waves, per-lane LDS stacks, lanes pull the next ray when idle --------------
-// Wave-local chunked fetch from a device queue: one global atomic per 64*4 items.
-struct WfFetcher {
-    uint32_t pos, end;     // wave-uniform
-};
-RT_DEV bool wf_fetch(WfFetcher &f, uint32_t *head, uint32_t count, bool want, uint32_t &item) {
-    // returns true for lanes that received an item; f is updated uniformly
+// ---- traversal kernels: persistent waves, per-lane LDS stacks ---------------------------------------------------
+// Every wave owns a contiguous slice of the queue (no atomics: the work per ray is statistically uniform and a
+// slice keeps neighbouring pixels together).  Lanes pull the next ray of the slice as soon as >= WF_REFILL lanes are
+// idle.  Control flow is "while-while": lanes walk inner nodes until >= WF_LEAF_BATCH of them wait at a leaf,
+// then the (expensive, division-heavy) triangle tests run for all waiting lanes together.
+#define WF_REFILL 16
+#define WF_LEAF_BATCH 20
+struct WfSlice { uint32_t pos, end; };
+RT_DEV WfSlice wf_slice(uint32_t count) {
+    uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t per = (count + nwaves - 1) / nwaves;
+    per = (per + 63u) & ~63u;
+    WfSlice s;
+    s.pos = wid * per < count ? wid * per : count;
+    s.end = s.pos + per < count ? s.pos + per : count;
+    return s;
+}
+// Hands queue positions to the lanes that want one; returns true for lanes that got `item`.
+RT_DEV bool wf_take(WfSlice &s, bool want, uint32_t &item) {
     unsigned long long need = __ballot(want);
-    bool got = false;
-    while (need) {
-        if (f.pos >= f.end) {
-            uint32_t base = 0;
-            if ((threadIdx.x & 63) == 0) base = atomicAdd(head, 256u);
-            base = __shfl(base, 0);
-            if (base >= count) { f.pos = f.end = 0xFFFFFFFFu; break; }
-            f.pos = base; f.end = base + 256u < count ? base + 256u : count;
-        }
-        uint32_t avail = f.end - f.pos;
-        uint32_t rank = (uint32_t)__popcll(need & ((1ull << (threadIdx.x & 63)) - 1ull));
-        if (want && !got && rank < avail) { item = f.pos + rank; got = true; }
-        uint32_t n = (uint32_t)__popcll(need);
-        uint32_t take = n < avail ? n : avail;
-        f.pos += take;
-        need = __ballot(want && !got);
-    }
+    uint32_t avail = s.end - s.pos;
+    uint32_t rank = (uint32_t)__popcll(need & ((1ull << (threadIdx.x & 63)) - 1ull));
+    bool got = want && rank < avail;
+    if (got) item = s.pos + rank;
+    uint32_t n = (uint32_t)__popcll(need);
+    s.pos += n < avail ? n : avail;
     return got;
 }
 
@@ -167,10 +203,8 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t(*stack)[64] = lds_stack[wave];
     const uint32_t *queue = W.q_trace[round & 1];
-    const uint32_t count = W.ctr[4 * round + 0];
-    uint32_t *head = W.ctr + 4 * round + 2;
-    WfFetcher fetch; fetch.pos = fetch.end = 0;
-    bool exhausted = false, active = false;
+    WfSlice slice = wf_slice(W.ctr[4 * round + 0]);
+    bool active = false;
     uint32_t slot = 0, cur = 0, hit = WF_MISS;
     int sp = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
@@ -179,13 +213,11 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
     unsigned long long n_nodes = 0, n_tris = 0;
     for (;;) {
         unsigned long long idle = __ballot(!active);
-        if (idle && !exhausted && (__popcll(idle) >= 16 || idle == ~0ull)) {
+        if (idle && slice.pos < slice.end && (__popcll(idle) >= WF_REFILL || idle == ~0ull)) {
             uint32_t item = 0;
-            bool got = wf_fetch(fetch, head, count, !active, item);
-            exhausted = fetch.pos == 0xFFFFFFFFu;
-            if (got) {
+            if (wf_take(slice, !active, item)) {
                 slot = queue[item];
-                const float4 *r = W.r0 + (size_t)slot * 4;
+                const float4 *r = wf_rec(W, slot);
                 float4 q0 = r[0], q1 = r[1];
                 o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                 ray = make_ray_inv(o, d);
@@ -194,9 +226,13 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
             }
         }
         if (!__ballot(active)) break;
-        if (active) {
-            bool pop = false;
-            if (!(cur & RT_LEAF_BIT)) {
+        // phase 1: inner nodes
+        for (;;) {
+            bool inner = active && !(cur & RT_LEAF_BIT);
+            unsigned long long m_inner = __ballot(inner);
+            unsigned long long m_leaf = __ballot(active && (cur & RT_LEAF_BIT));
+            if (!m_inner || __popcll(m_leaf) >= WF_LEAF_BATCH) break;
+            if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
@@ -210,30 +246,32 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
                     cur = swap ? c1 : c0;
                 } else if (h0) cur = c0;
                 else if (h1) cur = c1;
-                else pop = true;
-            } else {
-                if (cur != RT_EMPTY_LEAF) {
-                    uint32_t i = cur & ~RT_LEAF_BIT;
-                    for (;;) {
-                        TriIsect T = load_isect(S.tri_isect + i);
-                        if (COUNT) n_tris++;
-                        float t, u, v; bool inside;
-                        uint32_t best_i = hit & ~WF_INSIDE_BIT;
-                        if (tri_test(T, o, d, t, u, v, inside) && (t < best_t || (t == best_t && i < best_i))) {
-                            best_t = t; best_u = u; best_v = v; hit = i | (inside ? WF_INSIDE_BIT : 0u);
-                        }
-                        if (T.pad) break;
-                        i++;
-                    }
-                }
-                pop = true;
-            }
-            if (pop) {
-                if (sp == 0) { // traversal finished: publish the hit
-                    W.r0[(size_t)slot * 4 + 2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
+                else if (sp == 0) { // traversal finished: publish the hit
+                    wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
                     active = false;
                 } else cur = stack[--sp][lane];
             }
+        }
+        // phase 2: every lane waiting at a leaf tests its triangles
+        if (active && (cur & RT_LEAF_BIT)) {
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    TriIsect T = load_isect(S.tri_isect + i);
+                    if (COUNT) n_tris++;
+                    float t, u, v; bool inside;
+                    uint32_t best_i = hit & ~WF_INSIDE_BIT;
+                    if (tri_test(T, o, d, t, u, v, inside) && (t < best_t || (t == best_t && i < best_i))) {
+                        best_t = t; best_u = u; best_v = v; hit = i | (inside ? WF_INSIDE_BIT : 0u);
+                    }
+                    if (T.pad) break;
+                    i++;
+                }
+            }
+            if (sp == 0) {
+                wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
+                active = false;
+            } else cur = stack[--sp][lane];
         }
     }
     if (COUNT && counters) { atomicAdd(&counters[2], n_nodes); atomicAdd(&counters[3], n_tris); }
@@ -246,10 +284,8 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t(*stack)[64] = lds_stack[wave];
     const uint32_t *queue = W.q_light;
-    const uint32_t count = W.ctr[4 * round + 1];
-    uint32_t *head = W.ctr + 4 * round + 3;
-    WfFetcher fetch; fetch.pos = fetch.end = 0;
-    bool exhausted = false, active = false, descending = true;
+    WfSlice slice = wf_slice(W.ctr[4 * round + 1]);
+    bool active = false, descending = true;
     uint32_t slot = 0, cur = 0;
     int sp = 0;
     unsigned long long addmask = 0;
@@ -259,13 +295,11 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
     unsigned long long n_nodes = 0, n_tris = 0;
     for (;;) {
         unsigned long long idle = __ballot(!active);
-        if (idle && !exhausted && (__popcll(idle) >= 16 || idle == ~0ull)) {
+        if (idle && slice.pos < slice.end && (__popcll(idle) >= WF_REFILL || idle == ~0ull)) {
             uint32_t item = 0;
-            bool got = wf_fetch(fetch, head, count, !active, item);
-            exhausted = fetch.pos == 0xFFFFFFFFu;
-            if (got) {
+            if (wf_take(slice, !active, item)) {
                 slot = queue[item];
-                const float4 *r = W.r0 + (size_t)slot * 4;
+                const float4 *r = wf_rec(W, slot);
                 float4 q0 = r[0], q1 = r[1];
                 o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                 ray = make_ray_inv(o, d);
@@ -274,23 +308,13 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
             }
         }
         if (!__ballot(active)) break;
-        if (active) {
-            if (descending) {
-                if (cur & RT_LEAF_BIT) {
-                    float result = 0.f;
-                    if (cur != RT_EMPTY_LEAF) {
-                        uint32_t i = cur & ~RT_LEAF_BIT;
-                        for (;;) {
-                            bool last;
-                            if (COUNT) n_tris++;
-                            result += light_pdf_one(S.lights + i, o, d, last);
-                            if (last) break;
-                            i++;
-                        }
-                    }
-                    v = result;
-                    descending = false;
-                } else {
+        // phase 1: node steps and (cheap) return steps, until enough lanes wait at a leaf
+        for (;;) {
+            bool at_leaf = active && descending && (cur & RT_LEAF_BIT);
+            bool busy = active && !at_leaf;
+            if (!__ballot(busy) || __popcll(__ballot(at_leaf)) >= WF_LEAF_BATCH) break;
+            if (busy) {
+                if (descending) {
                     const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
                     float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                     if (COUNT) n_nodes++;
@@ -302,113 +326,163 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
                     else if (h0) cur = c0;
                     else if (h1) cur = c1;
                     else { v = 0.f; descending = false; }
-                }
-            } else {
-                if (sp == 0) { // sum complete
-                    reinterpret_cast<float *>(W.r0 + (size_t)slot * 4 + 2)[0] = v;
+                } else if (sp == 0) { // sum complete
+                    reinterpret_cast<float *>(wf_rec(W, slot) + 2)[0] = v;
                     active = false;
                 } else {
                     --sp;
                     uint32_t f = stack[sp][lane];
-                    if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;
+                    if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;       // left total + right total
                     else { addmask |= 1ull << sp; stack[sp++][lane] = __float_as_uint(v); cur = f; descending = true; }
                 }
             }
+        }
+        // phase 2: leaves
+        if (active && descending && (cur & RT_LEAF_BIT)) {
+            float result = 0.f;
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    bool last;
+                    if (COUNT) n_tris++;
+                    result += light_pdf_one(S.lights + i, o, d, last);
+                    if (last) break;
+                    i++;
+                }
+            }
+            v = result;
+            descending = false;
         }
     }
     if (COUNT && counters) { atomicAdd(&counters[2], n_nodes); atomicAdd(&counters[3], n_tris); }
 }
 
 // ---- shade: scene.cpp:89-156 for every traced pixel of this round -----------------------------------------------
+RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, const Pusher &to_light, const Pusher &next) {
+    float4 *r = wf_rec(W, slot);
+    float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+    F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+    Rng rng; rng.x = __float_as_uint(q1.z); rng.saved = q1.w;
+    uint32_t packed = __float_as_uint(q3.w);
+    int depth = (int)(packed & 15u);
+    rng.has_saved = (packed & 16u) != 0;
+    uint32_t sample = packed >> 5;
+    F3 accum = f3(q3.x, q3.y, q3.z);
+    uint32_t hit = __float_as_uint(q2.w);
+    if (hit == WF_MISS) { wf_finish_path(S, R, W, slot, depth, miss_color(S, d), accum, rng, sample, next); return; }
+    HitRec h;
+    h.idx = (int)(hit & ~WF_INSIDE_BIT); h.inside = (hit & WF_INSIDE_BIT) != 0; h.t = q2.x; h.u = q2.y; h.v = q2.z;
+    if (S.last_level_emission_only && depth + 1 >= R.ray_depth) {
+        // Deepest level: whatever Mix::sample / brdf / pdf produce, getColor returns its emission (see
+        // SceneView::last_level_emission_only).  Only the random draws must still happen, in order
+        // (distributions.h:257, then 3 normals | u1,u2 | index,u,v).
+        F3 emission = emission_fetch(S, h);
+        int comp = (int)(rng_u01(rng) * (float)S.n_components);
+        if (comp == 0) { rng_n01(rng); rng_n01(rng); rng_n01(rng); }
+        else if (comp == 2) { rng_u01(rng); rng_u01(rng); rng_u01(rng); }
+        else { rng_u01(rng); rng_u01(rng); }
+        wf_finish_path(S, R, W, slot, depth, emission, accum, rng, sample, next);
+        return;
+    }
+    F3 ng, base_color; float base_metallic; Shaded sh;
+    shade_fetch(S, h, ng, sh, base_color, base_metallic);
+    F3 x = o + h.t * d;                                                    // scene.cpp:104
+    F3 xo = x + 9.99999974737875163555e-05f * ng;                          // x + eps * geomNorma
+    int comp = (int)(rng_u01(rng) * (float)S.n_components);               // distributions.h:257
+    F3 nd;
+    if (comp == 0) nd = cosine_sample(rng, sh.sn);
+    else if (comp == 2) nd = light_sample(S, rng, xo);
+    else nd = vndf_sample(rng, sh.sn, d, sh.alpha);
+    F3 brdf = material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha);
+    const float epsf = 9.99999974737875163555e-05f;
+    if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) {             // scene.cpp:154-156
+        wf_finish_path(S, R, W, slot, depth, sh.emission, accum, rng, sample, next);
+        return;
+    }
+    float pdf = 0.f;                                                       // distributions.h:268-276, first two terms
+    pdf += cosine_pdf(sh.sn, nd);
+    pdf += vndf_pdf(sh.sn, nd, d, sh.alpha);
+    float4 *e = wf_entry(W, slot, depth);
+    e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, pdf);
+    e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sh.sn));
+    r[0] = make_float4(xo.x, xo.y, xo.z, nd.x);                           // the next ray doubles as the light query
+    r[1] = make_float4(nd.y, nd.z, __uint_as_float(rng.x), rng.saved);
+    r[2] = make_float4(0.f, q2.y, q2.z, q2.w);                            // light sum slot (stays 0 without lights)
+    r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(depth, rng.has_saved, sample)));
+    wf_push(to_light, slot);
+}
+
 __global__ __launch_bounds__(256) void wf_shade_kernel(SceneView S, RenderView R, WfView W, uint32_t round) {
+    __shared__ uint32_t buf_l[WF_BUF], buf_n[WF_BUF];
+    __shared__ uint32_t cnt_l, cnt_n, gbase;
+    if (threadIdx.x == 0) { cnt_l = 0; cnt_n = 0; }
+    __syncthreads();
+    Pusher to_light; to_light.buf = buf_l; to_light.cnt = &cnt_l;
+    Pusher next; next.buf = buf_n; next.cnt = &cnt_n;
     const uint32_t *queue = W.q_trace[round & 1];
     const uint32_t count = W.ctr[4 * round + 0];
-    uint32_t *next_queue = W.q_trace[(round + 1) & 1];
-    uint32_t *next_count = W.ctr + 4 * (round + 1) + 0;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        uint32_t slot = queue[i];
-        float4 *r = W.r0 + (size_t)slot * 4;
-        float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-        F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
-        Rng rng; rng.x = __float_as_uint(q1.z); rng.saved = q1.w;
-        uint32_t packed = __float_as_uint(q3.w);
-        int depth = (int)(packed & 15u);
-        rng.has_saved = (packed & 16u) != 0;
-        uint32_t sample = packed >> 5;
-        F3 accum = f3(q3.x, q3.y, q3.z);
-        uint32_t hit = __float_as_uint(q2.w);
-        if (hit == WF_MISS) {
-            wf_finish_path(S, R, W, slot, depth, miss_color(S, d), accum, rng, sample, next_queue, next_count);
-            continue;
-        }
-        HitRec h;
-        h.idx = (int)(hit & ~WF_INSIDE_BIT); h.inside = (hit & WF_INSIDE_BIT) != 0; h.t = q2.x; h.u = q2.y; h.v = q2.z;
-        F3 ng, base_color; float base_metallic; Shaded sh;
-        shade_fetch(S, h, ng, sh, base_color, base_metallic);
-        F3 x = o + h.t * d;                                                    // scene.cpp:104
-        F3 xo = x + 9.99999974737875163555e-05f * ng;                          // x + eps * geomNorma
-        int comp = (int)(rng_u01(rng) * (float)S.n_components);               // distributions.h:257
-        F3 nd;
-        if (comp == 0) nd = cosine_sample(rng, sh.sn);
-        else if (comp == 2) nd = light_sample(S, rng, xo);
-        else nd = vndf_sample(rng, sh.sn, d, sh.alpha);
-        F3 brdf = material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha);
-        const float epsf = 9.99999974737875163555e-05f;
-        if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) {             // scene.cpp:154-156
-            wf_finish_path(S, R, W, slot, depth, sh.emission, accum, rng, sample, next_queue, next_count);
-            continue;
-        }
-        float pdf = 0.f;                                                       // distributions.h:268-276, first two terms
-        pdf += cosine_pdf(sh.sn, nd);
-        pdf += vndf_pdf(sh.sn, nd, d, sh.alpha);
-        float4 *e = W.stack + ((size_t)depth * W.n_slots + slot) * 2;
-        e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, pdf);
-        e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sh.sn));
-        r[0] = make_float4(xo.x, xo.y, xo.z, nd.x);                           // the next ray doubles as the light query
-        r[1] = make_float4(nd.y, nd.z, __uint_as_float(rng.x), rng.saved);
-        r[2] = make_float4(0.f, q2.y, q2.z, q2.w);                            // light sum slot (stays 0 without lights)
-        r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(depth, rng.has_saved, sample)));
-        wf_push(W.q_light, W.ctr + 4 * round + 1, slot);
+    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + 4 * (round + 1) + 0;
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        uint32_t i = base + threadIdx.x;
+        if (i < count) wf_shade_item(S, R, W, queue[i], to_light, next);
+        __syncthreads();
+        if (cnt_l > WF_BUF - 256) wf_flush(to_light, W.q_light, W.ctr + 4 * round + 1, &gbase);
+        if (cnt_n > WF_BUF - 256) wf_flush(next, next_queue, next_count, &gbase);
     }
+    __syncthreads();
+    wf_flush(to_light, W.q_light, W.ctr + 4 * round + 1, &gbase);
+    wf_flush(next, next_queue, next_count, &gbase);
 }
 
 // ---- update: scene.cpp:158-164 for every pixel that reached the pdf stage -----------------------------------------
+RT_DEV void wf_update_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, const Pusher &next) {
+    float4 *r = wf_rec(W, slot);
+    float4 q1 = r[1], q2 = r[2], q3 = r[3];
+    uint32_t packed = __float_as_uint(q3.w);
+    int depth = (int)(packed & 15u);
+    uint32_t sample = packed >> 5;
+    F3 accum = f3(q3.x, q3.y, q3.z);
+    float4 *e = wf_entry(W, slot, depth);
+    float4 e0 = e[0], e1 = e[1];
+    F3 emission = f3(e0.x, e0.y, e0.z), brdf = f3(e1.x, e1.y, e1.z);
+    float pdf = e0.w;
+    if (S.n_components == 3) pdf += q2.x / (float)S.n_lights;             // distributions.h:123,273
+    pdf = pdf / (float)S.n_components;                                     // :278
+    float k = (float)(1. / (double)pdf * fabs((double)e1.w));              // scene.cpp:159
+    F3 mult = k * brdf;
+    bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
+    if (clamp || depth + 1 >= R.ray_depth) {
+        // clamp hack (scene.cpp:161-163): the path returns the emission; at the last level the inner call
+        // returns 0, i.e. emission + mult * 0 evaluated literally.
+        Rng rng; rng.x = __float_as_uint(q1.z); rng.saved = q1.w; rng.has_saved = (packed & 16u) != 0;
+        F3 tail = emission;
+        int levels = depth;
+        if (!clamp) { e[1] = make_float4(mult.x, mult.y, mult.z, e1.w); tail = f3(0.f, 0.f, 0.f); levels = depth + 1; }
+        wf_finish_path(S, R, W, slot, levels, tail, accum, rng, sample, next);
+    } else {
+        e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
+        r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float((packed & ~15u) | (uint32_t)(depth + 1)));
+        wf_push(next, slot);
+    }
+}
+
 __global__ __launch_bounds__(256) void wf_update_kernel(SceneView S, RenderView R, WfView W, uint32_t round) {
+    __shared__ uint32_t buf_n[WF_BUF];
+    __shared__ uint32_t cnt_n, gbase;
+    if (threadIdx.x == 0) cnt_n = 0;
+    __syncthreads();
+    Pusher next; next.buf = buf_n; next.cnt = &cnt_n;
     const uint32_t *queue = W.q_light;
     const uint32_t count = W.ctr[4 * round + 1];
-    uint32_t *next_queue = W.q_trace[(round + 1) & 1];
-    uint32_t *next_count = W.ctr + 4 * (round + 1) + 0;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        uint32_t slot = queue[i];
-        float4 *r = W.r0 + (size_t)slot * 4;
-        float4 q1 = r[1], q2 = r[2], q3 = r[3];
-        uint32_t packed = __float_as_uint(q3.w);
-        int depth = (int)(packed & 15u);
-        uint32_t sample = packed >> 5;
-        F3 accum = f3(q3.x, q3.y, q3.z);
-        float4 *e = W.stack + ((size_t)depth * W.n_slots + slot) * 2;
-        float4 e0 = e[0], e1 = e[1];
-        F3 emission = f3(e0.x, e0.y, e0.z), brdf = f3(e1.x, e1.y, e1.z);
-        float pdf = e0.w;
-        if (S.n_components == 3) pdf += q2.x / (float)S.n_lights;             // distributions.h:123,273
-        pdf = pdf / (float)S.n_components;                                     // :278
-        float k = (float)(1. / (double)pdf * fabs((double)e1.w));              // scene.cpp:159
-        F3 mult = k * brdf;
-        bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
-        if (clamp || depth + 1 >= R.ray_depth) {
-            // clamp hack (scene.cpp:161-163): the path returns the emission; at the last level the inner call
-            // returns 0, i.e. emission + mult * 0 evaluated literally.
-            Rng rng; rng.x = __float_as_uint(q1.z); rng.saved = q1.w; rng.has_saved = (packed & 16u) != 0;
-            F3 tail = emission;
-            int levels = depth;
-            if (!clamp) { e[1] = make_float4(mult.x, mult.y, mult.z, e1.w); tail = f3(0.f, 0.f, 0.f); levels = depth + 1; }
-            wf_finish_path(S, R, W, slot, levels, tail, accum, rng, sample, next_queue, next_count);
-        } else {
-            e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
-            r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float((packed & ~15u) | (uint32_t)(depth + 1)));
-            wf_push(next_queue, next_count, slot);
-        }
+    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + 4 * (round + 1) + 0;
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        uint32_t i = base + threadIdx.x;
+        if (i < count) wf_update_item(S, R, W, queue[i], next);
+        __syncthreads();
+        if (cnt_n > WF_BUF - 256) wf_flush(next, next_queue, next_count, &gbase);
     }
+    __syncthreads();
+    wf_flush(next, next_queue, next_count, &gbase);
 }
 
 } // namespace dev

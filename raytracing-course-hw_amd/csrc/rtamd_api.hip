@@ -214,6 +214,13 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         V.n_tris = desc->n_triangles;
         V.n_lights = (uint32_t)P.lights.size();
         V.n_components = P.lights.empty() ? 2u : 3u; // scene.cpp:65-74
+        V.last_level_emission_only = 1;
+        for (uint32_t i = 0; i < desc->n_materials; i++) {
+            const rt_material &m = desc->materials[i];
+            if (!(m.metallic_factor >= 0 && m.metallic_factor <= 1 && m.base_color[0] >= 0 && m.base_color[1] >= 0 && m.base_color[2] >= 0))
+                V.last_level_emission_only = 0;
+        }
+        if (getenv("RTAMD_NO_LAST_LEVEL_SHORTCUT")) V.last_level_emission_only = 0;
         V.env_image = P.env_image;
         for (int k = 0; k < 3; k++) {
             V.cam_pos[k] = desc->camera.position[k]; V.cam_right[k] = desc->camera.right[k];
@@ -304,8 +311,7 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_rounds < rounds) {
         scene->free_wf();
         auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); scene->wf_allocs.push_back(p); return p; };
-        scene->wf.r0 = (float4 *)alloc(n_slots * 64);
-        scene->wf.stack = (float4 *)alloc(n_slots * 32 * (size_t)R.ray_depth);
+        scene->wf.r0 = (float4 *)alloc(n_slots * (64 + 32 * (size_t)R.ray_depth));
         scene->wf.q_trace[0] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_trace[1] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_light = (uint32_t *)alloc(n_slots * 4);
@@ -314,6 +320,7 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     }
     dev::WfView W = scene->wf;
     W.n_slots = (uint32_t)n_slots;
+    W.stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
     HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * 16, stream));
     const uint32_t persistent_blocks = (uint32_t)scene->n_cus * 5u;   // 5 x 256 threads x 32 KB LDS per CU
     uint32_t shade_blocks = (uint32_t)((n_slots + 255) / 256);

@@ -198,7 +198,7 @@ RT_DEV bool wf_take(WfSlice &s, bool want, uint32_t &item) {
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters) {
+__global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters, int refill, int leaf_batch) {
     __shared__ uint32_t lds_stack[4][WF_STACK][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t(*stack)[64] = lds_stack[wave];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
     unsigned long long n_nodes = 0, n_tris = 0;
     for (;;) {
         unsigned long long idle = __ballot(!active);
-        if (idle && slice.pos < slice.end && (__popcll(idle) >= WF_REFILL || idle == ~0ull)) {
+        if (idle && slice.pos < slice.end && (__popcll(idle) >= refill || idle == ~0ull)) {
             uint32_t item = 0;
             if (wf_take(slice, !active, item)) {
                 slot = queue[item];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
             bool inner = active && !(cur & RT_LEAF_BIT);
             unsigned long long m_inner = __ballot(inner);
             unsigned long long m_leaf = __ballot(active && (cur & RT_LEAF_BIT));
-            if (!m_inner || __popcll(m_leaf) >= WF_LEAF_BATCH) break;
+            if (!m_inner || __popcll(m_leaf) >= leaf_batch) break;
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
 
 // All-hits light sum (FiguresMix::getTotalPdf, distributions.h:148-165) with the reference's addition tree.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters) {
+__global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters, int refill, int leaf_batch) {
     __shared__ uint32_t lds_stack[4][WF_STACK][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t(*stack)[64] = lds_stack[wave];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
     unsigned long long n_nodes = 0, n_tris = 0;
     for (;;) {
         unsigned long long idle = __ballot(!active);
-        if (idle && slice.pos < slice.end && (__popcll(idle) >= WF_REFILL || idle == ~0ull)) {
+        if (idle && slice.pos < slice.end && (__popcll(idle) >= refill || idle == ~0ull)) {
             uint32_t item = 0;
             if (wf_take(slice, !active, item)) {
                 slot = queue[item];
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
         for (;;) {
             bool at_leaf = active && descending && (cur & RT_LEAF_BIT);
             bool busy = active && !at_leaf;
-            if (!__ballot(busy) || __popcll(__ballot(at_leaf)) >= WF_LEAF_BATCH) break;
+            if (!__ballot(busy) || __popcll(__ballot(at_leaf)) >= leaf_batch) break;
             if (busy) {
                 if (descending) {
                     const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);

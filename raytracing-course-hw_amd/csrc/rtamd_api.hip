@@ -322,17 +322,22 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     W.n_slots = (uint32_t)n_slots;
     W.stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
     HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * 16, stream));
-    const uint32_t persistent_blocks = (uint32_t)scene->n_cus * 5u;   // 5 x 256 threads x 32 KB LDS per CU
+    uint32_t blocks_per_cu = 4u;                                      // measured best (5 fit: 5 x 32 KB LDS per CU)
+    if (const char *e = getenv("RTAMD_WF_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : blocks_per_cu;
+    const uint32_t persistent_blocks = (uint32_t)scene->n_cus * blocks_per_cu;
+    auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
+    const int t_refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL), t_batch = env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH);
+    const int l_refill = env_int("RTAMD_LIGHT_REFILL", WF_REFILL), l_batch = env_int("RTAMD_LIGHT_LEAF_BATCH", WF_LEAF_BATCH);
     uint32_t shade_blocks = (uint32_t)((n_slots + 255) / 256);
     if (shade_blocks > (uint32_t)scene->n_cus * 16u) shade_blocks = (uint32_t)scene->n_cus * 16u;
     unsigned long long *ctrs = count ? scene->d_counters : nullptr;
     hipLaunchKernelGGL(dev::wf_init_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream, scene->view, R, W);
     for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
-        if (count) hipLaunchKernelGGL(dev::wf_trace_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
-        else hipLaunchKernelGGL(dev::wf_trace_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
+        if (count) hipLaunchKernelGGL(dev::wf_trace_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch);
+        else hipLaunchKernelGGL(dev::wf_trace_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch);
         hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
-        if (count) hipLaunchKernelGGL(dev::wf_light_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
-        else hipLaunchKernelGGL(dev::wf_light_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs);
+        if (count) hipLaunchKernelGGL(dev::wf_light_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch);
+        else hipLaunchKernelGGL(dev::wf_light_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch);
         hipLaunchKernelGGL(dev::wf_update_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
     }
     HIP_CHECK(hipGetLastError());

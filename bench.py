@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--workload", default="synth_room_v1_1920x1080x256", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (profiling only: the result is not the headline metric)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = per-GPU work fixed (frame grows to N x 1920x1080 pixels, 16:9), strong = the 1920x1080 frame split N ways")
+    ap.add_argument("--emulate-shards", type=int, default=0, help="diagnostic: render only shard 0 of N on this one GPU (what each GPU does at --gpus N, without the gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded baseline sample")
     args = ap.parse_args()
@@ -75,6 +78,13 @@ def main():
 
     wl = WORKLOADS[args.workload]
     W, H, SPP = wl["width"], wl["height"], (args.spp if args.spp > 0 else wl["spp"])
+    base_w, base_h = W, H
+    if world > 1 and args.scaling == "weak":
+        # Weak scaling: every GPU keeps one 1920x1080 frame's worth of pixels; the frame grows by sqrt(N) per side
+        # (N=4 is exactly the 3840x2160 of BASELINE.json configs[4]).  A pixel's samples are serial in replay mode,
+        # so pixels are the only axis that can grow.
+        k = math.sqrt(world)
+        W, H = int(round(W * k / 8.0)) * 8, int(round(H * k / 8.0)) * 8
     tmp = tempfile.mkdtemp(prefix=f"synth_room_r{rank}_")
     t0 = time.time()
     gltf, n_tris = gen_synth_room.generate(tmp, wl["spheres"], wl["segs"], wl["rings"])
@@ -84,7 +94,8 @@ def main():
     info = scene.info()
 
     stream = torch.cuda.current_stream()
-    params = rt.make_params(W, H, SPP, shard_index=rank, shard_count=world, tile=32, stream=stream.cuda_stream)
+    emu = args.emulate_shards if (args.emulate_shards > 1 and world == 1) else 0
+    params = rt.make_params(W, H, SPP, shard_index=rank, shard_count=(emu or world), tile=32, stream=stream.cuda_stream)
     n_elems = rt.lib.rt_output_elems(params)
     out_rgb = torch.zeros(n_elems, dtype=torch.float32, device="cuda")
     out_rgb8 = torch.zeros(n_elems, dtype=torch.uint8, device="cuda")
@@ -117,6 +128,12 @@ def main():
         elapsed = float(t.item())
     total_samples = W * H * SPP * args.steps
     value = total_samples / elapsed / 1e6
+    if emu and rank == 0:
+        print(json.dumps({"diagnostic": f"shard 0 of {emu} on one GPU", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "shard_samples": int(st.samples), "shard_msamples_per_s": round(st.samples * args.steps / elapsed / 1e6, 3),
+                          "projected_aggregate_if_all_shards_equal": round(st.samples * emu * args.steps / elapsed / 1e6, 3)}), flush=True)
+        scene.close()
+        return
 
     result = None
     if rank == 0:
@@ -158,9 +175,10 @@ def main():
         headline = args.workload.endswith("1920x1080x256") and args.spp <= 0
         result = {"metric": "Msamples/sec at 1920x1080x256spp" if headline else f"Msamples/sec ({args.workload}, spp={SPP}; NOT the headline config)",
                   "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                  "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                  "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                  "scaling": "strong" if (world == 1 or args.scaling == "strong") else "weak",
                   "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": args.workload, "scene": "synth_room_v1 (seed 20241223)", "triangles": int(info.n_triangles),
+                  "config": {"workload": args.workload if (W, H) == (base_w, base_h) else f"{args.workload} grown to {W}x{H} ({world} x {base_w}x{base_h} pixels)", "scene": "synth_room_v1 (seed 20241223)", "triangles": int(info.n_triangles),
                              "emissive_triangles": int(info.n_lights), "width": W, "height": H, "spp": SPP, "ray_depth": 6,
                              "parallelism": f"pixel tiles 32x32 round-robin over {world} GPU(s)" + (", RCCL gather of u8 tiles" if world > 1 else ""),
                              "bvh_nodes": int(info.n_bvh_nodes), "scene_prep_ms": round(info.prep_ms, 1), "scene_upload_ms": round(info.upload_ms, 1),

@@ -66,12 +66,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal on a one-GPU box: RTAMD_BENCH_REHEARSAL=1 puts every rank on cuda:0 and gathers over gloo, which
+    # exercises all of the N>1 logic except RCCL itself (RCCL refuses two ranks on one device).
+    rehearsal = os.environ.get("RTAMD_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
 
     rt = importlib.import_module("raytracing-course-hw_amd")
     import gen_synth_room
@@ -100,18 +107,20 @@ def main():
     out_rgb = torch.zeros(n_elems, dtype=torch.float32, device="cuda")
     out_rgb8 = torch.zeros(n_elems, dtype=torch.uint8, device="cuda")
     rtd = importlib.import_module("raytracing-course-hw_amd.distributed")
-    kernel_ms = []
+    kernel_ms, dom_ms, dom_launches = [], [], []
 
     def step():
         st = scene.render_device(params, out_rgb.data_ptr(), out_rgb8.data_ptr())
         kernel_ms.append(st.kernel_ms)
+        dom_ms.append(st.dominant_kernel_ms)
+        dom_launches.append(st.dominant_kernel_launches)
         if world > 1:  # the one exchange step: tonemapped tiles to rank 0 over RCCL/xGMI, assembled into the frame there
             rtd.gather_frame(dist, out_rgb8, W, H, SPP, rank, world, 32)
         return st
 
     for _ in range(args.warmup):
         step()
-    kernel_ms.clear()
+    kernel_ms.clear(); dom_ms.clear(); dom_launches.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -123,7 +132,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_samples = W * H * SPP * args.steps
@@ -147,11 +156,23 @@ def main():
         t_bar = 1.0
         bps = algorithmic_bytes_per_sample(info.n_triangles, info.n_lights, s_bar, p_bar, t_bar, SPP)
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        samples_per_launch = st.samples  # this rank's share
-        achieved = bps * samples_per_launch / (k_ms * 1e-3) / 1e9
+        samples_per_render = st.samples  # this rank's share
+        render_gbs = bps * samples_per_render / (k_ms * 1e-3) / 1e9
+        # Dominant kernel = wf_trace_kernel (closest-hit traversal; ~41 % of GPU time, profiles/).  Its algorithmic
+        # bytes per query are the root-to-leaf part of SURVEY 8(d): (ceil(log2 N_tri)+1) nodes x 32 B + 36 B positions.
+        wavefront = st.dominant_kernel_launches > 1
+        q_bytes = (math.ceil(math.log2(max(info.n_triangles, 2))) + 1) * 32 + 36
+        n_l = max(1, sum(dom_launches))
+        launch_ms = sum(dom_ms) / n_l                                      # average launch duration, HIP events on the launch stream
+        queries_per_launch = s_bar * samples_per_render * len(dom_ms) / n_l
+        achieved = (q_bytes * queries_per_launch / (launch_ms * 1e-3) / 1e9) if wavefront else render_gbs
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                    "kernel": "render_hw8_kernel", "kernel_ms": round(k_ms, 3), "bytes_per_sample": round(bps, 1),
+                    "kernel": "wf_trace_kernel" if wavefront else "render_hw8_kernel",
+                    "kernel_avg_launch_ms": round(launch_ms, 4), "kernel_launches_per_step": int(n_l / max(1, len(dom_ms))),
+                    "kernel_bytes_per_query": q_bytes, "queries_per_launch": round(queries_per_launch, 1),
+                    "whole_render": {"achieved": round(render_gbs, 3), "frac": round(render_gbs / HBM_PEAK_GBS, 6), "gpu_ms": round(k_ms, 3),
+                                     "bytes_per_sample": round(bps, 1)},
                     "s_bar": round(s_bar, 3), "p_bar": round(p_bar, 3),
                     "node_visits_per_sample": round(cst.node_visits / max(1, cst.samples), 2),
                     "triangle_tests_per_sample": round(cst.triangle_tests / max(1, cst.samples), 2)}

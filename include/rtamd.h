@@ -147,7 +147,8 @@ typedef struct rt_stats {
     uint64_t closest_hit_queries, light_pdf_queries; /* RT_FLAG_COUNTERS */
     uint64_t node_visits, triangle_tests;            /* RT_FLAG_COUNTERS */
     uint32_t launches;
-    uint32_t reserved;
+    uint32_t dominant_kernel_launches; /* launches of the dominant kernel (wavefront path: wf_trace_kernel) */
+    double dominant_kernel_ms;         /* sum of their HIP-event durations on the launch stream */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

@@ -81,6 +81,7 @@ struct rt_scene {
     dev::WfView wf{};
     size_t wf_slots = 0, wf_levels = 0, wf_rounds = 0;
     std::vector<void *> wf_allocs;
+    std::vector<hipEvent_t> ev_pool; // brackets every launch of the dominant kernel when stats are requested
     void free_wf() {
         for (void *p : wf_allocs) (void)hipFree(p);
         wf_allocs.clear();
@@ -91,6 +92,7 @@ struct rt_scene {
         for (void *p : allocations) (void)hipFree(p);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
 };
 
@@ -305,7 +307,7 @@ size_t rt_output_elems(const rt_render_params *p) {
 
 // Wavefront driver: spp * ray_depth rounds of trace / shade / light / update (device/rt_wavefront.h).
 // No host synchronisation inside: queue lengths live in device memory, one counter block per round.
-static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count) {
+static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     const size_t n_slots = (size_t)n_work * 64;
     const size_t rounds = (size_t)R.samples * R.ray_depth;
     if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_rounds < rounds) {
@@ -332,9 +334,12 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     if (shade_blocks > (uint32_t)scene->n_cus * 16u) shade_blocks = (uint32_t)scene->n_cus * 16u;
     unsigned long long *ctrs = count ? scene->d_counters : nullptr;
     hipLaunchKernelGGL(dev::wf_init_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream, scene->view, R, W);
+    if (time_trace) while (scene->ev_pool.size() < 2 * rounds) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
+        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r], stream));
         if (count) hipLaunchKernelGGL(dev::wf_trace_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch);
         else hipLaunchKernelGGL(dev::wf_trace_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch);
+        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r + 1], stream));
         hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
         if (count) hipLaunchKernelGGL(dev::wf_light_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch);
         else hipLaunchKernelGGL(dev::wf_light_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch);
@@ -399,7 +404,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
             if (use_wavefront) {
-                launch_wavefront(scene, R, n_work, stream, count);
+                launch_wavefront(scene, R, n_work, stream, count, stats != nullptr);
                 launches = 1 + 4 * (uint32_t)R.samples * (uint32_t)R.ray_depth;
             } else if (p->integrator == RT_INTEGRATOR_HW1) {
                 uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
@@ -442,6 +447,12 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->kernel_ms = ms;
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
+            if (use_wavefront && blocks) {
+                size_t rounds = (size_t)R.samples * R.ray_depth;
+                double sum = 0;
+                for (size_t r = 0; r < rounds; r++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * r], scene->ev_pool[2 * r + 1])); sum += e; }
+                stats->dominant_kernel_ms = sum; stats->dominant_kernel_launches = (uint32_t)rounds;
+            } else { stats->dominant_kernel_ms = ms; stats->dominant_kernel_launches = launches; }
             // pixels of this shard that lie inside the image
             uint64_t px = 0;
             for (uint32_t st = 0; st < R.n_shard_tiles; st++) {

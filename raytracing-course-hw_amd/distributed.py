@@ -26,6 +26,8 @@ def gather_frame(dist, local, width, height, samples, rank, world, tile=32):
     import torch
     sizes = shard_elems(width, height, samples, world, tile)
     pad = max(sizes)
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        local = local.cpu()  # gloo moves host memory; RCCL (backend "nccl") keeps the tiles on the GPUs
     send = local
     if local.numel() != pad:
         send = torch.zeros(pad, dtype=local.dtype, device=local.device)

@@ -9,6 +9,7 @@
 #include "material.h"
 #include "color.h"
 #include "primitives.h"
+#include "transition.h"
 #include "../../include/rtamd.h"
 #include <vector>
 #include <cstring>
@@ -86,6 +87,34 @@ void ref8_brdf(float base_metallic, const float *base_color, const float *l, con
     MaterialModel m(base_metallic, v3(base_color));
     Vec3 r = m.brdf(v3(l), v3(v), v3(n), v3(color), metallic, alpha);
     out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+// Node transform chain exactly as hw8/src/sceneio.cpp:125-134 (calculateTransitions) and :247-293 (loadFigures) apply it:
+// chain = n_levels x {t3, q4(x,y,z,w), s3}, outermost parent first; if matrix16 != NULL the innermost node uses that
+// column-major matrix instead (sceneio.cpp:67-74).
+void ref8_transform_chain(int n_levels, const float *chain, const float *matrix16, int n, const float *pos, const float *nrm, const float *tan4,
+                          float *out_pos, float *out_nrm, float *out_tan) {
+    std::vector<Transition> local;
+    for (int l = 0; l < n_levels; l++) {
+        const float *c = chain + 10 * l;
+        local.push_back(Transition(Vec3(c[0], c[1], c[2]), Quaternion(c[3], c[4], c[5], c[6]), Vec3(c[7], c[8], c[9])));
+    }
+    if (matrix16) {
+        float m[4][4];
+        for (size_t i = 0; i < 16; i++) m[i % 4][i / 4] = matrix16[i];
+        local.back() = Transition(m);
+    }
+    Transition total = local.back();
+    for (int l = n_levels - 2; l >= 0; l--) total = local[l].compose(total);
+    Transition normalT = total.inverted().transposed();
+    Vec3 shift = total.apply({0, 0, 0});
+    for (int i = 0; i < n; i++) {
+        Vec3 p = total.apply(v3(pos + 3 * i));
+        Vec3 nn = normalT.apply(v3(nrm + 3 * i)).normalize();
+        Vec3 tt = (total.apply(v3(tan4 + 4 * i)) - shift).normalize();
+        out_pos[3 * i] = p.x; out_pos[3 * i + 1] = p.y; out_pos[3 * i + 2] = p.z;
+        out_nrm[3 * i] = nn.x; out_nrm[3 * i + 1] = nn.y; out_nrm[3 * i + 2] = nn.z;
+        out_tan[3 * i] = tt.x; out_tan[3 * i + 1] = tt.y; out_tan[3 * i + 2] = tt.z;
+    }
 }
 void ref8_tonemap(const float *rgb, uint8_t *out3) {
     auto a = toExternColorFormat(gamma_corrected(aces_tonemap(v3(rgb))));

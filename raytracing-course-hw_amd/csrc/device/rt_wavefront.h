@@ -211,10 +211,12 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
     RayInv ray = make_ray_inv(o, d);
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
     unsigned long long n_nodes = 0, n_tris = 0;
+    unsigned long long w_node_iters = 0, w_leaf_phases = 0, w_leaf_lanes = 0, w_refills = 0; // wave-level (lane 0 reports)
     for (;;) {
         unsigned long long idle = __ballot(!active);
         if (idle && slice.pos < slice.end && (__popcll(idle) >= refill || idle == ~0ull)) {
             uint32_t item = 0;
+            if (COUNT) w_refills++;
             if (wf_take(slice, !active, item)) {
                 slot = queue[item];
                 const float4 *r = wf_rec(W, slot);
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
             unsigned long long m_inner = __ballot(inner);
             unsigned long long m_leaf = __ballot(active && (cur & RT_LEAF_BIT));
             if (!m_inner || __popcll(m_leaf) >= leaf_batch) break;
+            if (COUNT) w_node_iters++;
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
             }
         }
         // phase 2: every lane waiting at a leaf tests its triangles
+        if (COUNT) { unsigned long long ml = __ballot(active && (cur & RT_LEAF_BIT)); if (ml) { w_leaf_phases++; w_leaf_lanes += __popcll(ml); } }
         if (active && (cur & RT_LEAF_BIT)) {
             if (cur != RT_EMPTY_LEAF) {
                 uint32_t i = cur & ~RT_LEAF_BIT;
@@ -274,7 +278,11 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
             } else cur = stack[--sp][lane];
         }
     }
-    if (COUNT && counters) { atomicAdd(&counters[2], n_nodes); atomicAdd(&counters[3], n_tris); }
+    if (COUNT && counters) {
+        atomicAdd(&counters[2], n_nodes); atomicAdd(&counters[3], n_tris);
+        atomicAdd(&counters[8], n_nodes); atomicAdd(&counters[9], n_tris);
+        if (lane == 0) { atomicAdd(&counters[4], w_node_iters); atomicAdd(&counters[5], w_leaf_phases); atomicAdd(&counters[6], w_leaf_lanes); atomicAdd(&counters[7], w_refills); }
+    }
 }
 
 // All-hits light sum (FiguresMix::getTotalPdf, distributions.h:148-165) with the reference's addition tree.

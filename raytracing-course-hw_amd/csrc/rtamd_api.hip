@@ -141,7 +141,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s->flavor = RT_INTEGRATOR_HW3;
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
-            HIP_CHECK(hipMalloc((void **)&s->d_counters, 64));
+            HIP_CHECK(hipMalloc((void **)&s->d_counters, 128));
             s->allocations.push_back(s->d_counters);
             HIP_CHECK(hipEventCreate(&s->ev_start));
             HIP_CHECK(hipEventCreate(&s->ev_stop));
@@ -180,7 +180,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s->flavor = RT_INTEGRATOR_HW6;
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
-            HIP_CHECK(hipMalloc((void **)&s->d_counters, 64));
+            HIP_CHECK(hipMalloc((void **)&s->d_counters, 128));
             s->allocations.push_back(s->d_counters);
             HIP_CHECK(hipEventCreate(&s->ev_start));
             HIP_CHECK(hipEventCreate(&s->ev_stop));
@@ -233,7 +233,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         V.tan_fov_y = (float)std::tan((double)(desc->camera.fov_y / 2)); // scene.cpp:180 (host libm, like the reference)
         HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
         s->allocations.push_back(s->d_work_counter);
-        HIP_CHECK(hipMalloc((void **)&s->d_counters, 64));
+        HIP_CHECK(hipMalloc((void **)&s->d_counters, 128));
         s->allocations.push_back(s->d_counters);
         HIP_CHECK(hipEventCreate(&s->ev_start));
         HIP_CHECK(hipEventCreate(&s->ev_stop));
@@ -387,7 +387,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         R.inv_samples = (float)(1.0 / R.samples);
         uint32_t n_work = R.n_shard_tiles * (uint32_t)((R.tile_w >> 3) * (R.tile_h >> 3));
         HIP_CHECK(hipMemsetAsync(scene->d_work_counter, 0, 4, stream));
-        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 32, stream));
+        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 128, stream));
         uint32_t blocks = (uint32_t)scene->n_cus * 16u;
         if (blocks > n_work) blocks = n_work;
         // Kernel organisation: "wavefront" (default) or the single persistent "megakernel" (RTAMD_KERNEL=mega,
@@ -429,8 +429,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipEventRecord(scene->ev_stop, stream));
         if (own_rgb) HIP_CHECK(hipMemcpyAsync(out_rgb, d_rgb, elems * sizeof(float), hipMemcpyDeviceToHost, stream));
         if (own_rgb8) HIP_CHECK(hipMemcpyAsync(out_rgb8, d_rgb8, elems, hipMemcpyDeviceToHost, stream));
-        unsigned long long h_cnt[4] = {0, 0, 0, 0};
-        if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 32, hipMemcpyDeviceToHost, stream));
+        unsigned long long h_cnt[16] = {0};
+        if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 128, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
             size_t rounds = (size_t)R.samples * R.ray_depth;
@@ -438,6 +438,9 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
             for (size_t r = 0; r < rounds; r++) { h_cnt[0] += ctr[4 * r]; if (scene->info.n_lights) h_cnt[1] += ctr[4 * r + 1]; }
         }
+        if (count && getenv("RTAMD_DEBUG_COUNTERS"))
+            fprintf(stderr, "[rtamd] trace kernel: wave node-iterations %llu, leaf phases %llu (lanes %llu), refills %llu; lane node visits %llu, tri tests %llu\n",
+                    h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7], h_cnt[8], h_cnt[9]);
         if (own_rgb) { (void)hipFree(d_rgb); own_rgb = false; }
         if (own_rgb8) { (void)hipFree(d_rgb8); own_rgb8 = false; }
         if (stats) {

@@ -44,6 +44,21 @@ def main():
         out[name + "_rgb"], out[name + "_rgb8"] = rgb, rgb8
         print(name, rgb.shape, float(rgb.mean()))
     np.savez_compressed(os.path.join(HERE, "pins_hw6_render.npz"), **out)
+    # loader arithmetic through the reference's own transition.h (node chains, inverse-transpose normals, tangents)
+    import tempfile as _tf
+    with _tf.TemporaryDirectory() as td:
+        _, lc = pin_cases.loader_case(td)
+    L8.ref8_transform_chain.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    out = {}
+    n = lc["pos"].shape[0]
+    for tag, levels, chain, matrix in (("chain", 3, lc["chain"], None), ("matrix", 1, np.array([0, 0, 0, 0, 0, 0, 1, 1, 1, 1], np.float32), lc["matrix"])):
+        op, on, ot = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        ch = np.ascontiguousarray(chain, np.float32)
+        L8.ref8_transform_chain(levels, ch.ctypes.data, matrix.ctypes.data if matrix is not None else None, n, lc["pos"].ctypes.data,
+                                lc["nrm"].ctypes.data, lc["tan"].ctypes.data, op.ctypes.data, on.ctypes.data, ot.ctypes.data)
+        out[tag + "_pos"], out[tag + "_nrm"], out[tag + "_tan"] = op, on, ot
+    np.savez_compressed(os.path.join(HERE, "pins_loader_transforms.npz"), **out)
+    print("loader transforms", {k: v.shape for k, v in out.items()})
     # byte-level pins through the reference's own unmodified CLI programs (hw1, hw3)
     import hashlib
     import subprocess

@@ -133,3 +133,45 @@ def hw6_soup(n=300, seed=17):
 
 HW6_CASES = {"practice6_1": (lambda: load_hw6("practice6_1"), 48, 36, 4), "practice6_2": (lambda: load_hw6("practice6_2"), 20, 20, 2),
              "hw6_soup": (hw6_soup, 48, 40, 8)}
+
+
+def loader_case(tmpdir):
+    """A small glTF with a three-level TRS chain (non-uniform scale, general rotations) on one mesh and a `matrix` node on
+    another; returns (gltf path, per-mesh dicts with the raw vertex data and the node chain)."""
+    import json
+    rng = np.random.default_rng(99)
+    n = 24
+    pos = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    nrm = unit(rng.normal(0, 1, (n, 3)))
+    tan = np.concatenate([unit(rng.normal(0, 1, (n, 3))), np.ones((n, 1), np.float32)], axis=1).astype(np.float32)
+    uv = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    idx = np.arange(n, dtype=np.uint16)
+    blob = b"".join(a.tobytes() for a in (pos, nrm, uv, tan, idx))
+    offs = np.cumsum([0, pos.nbytes, nrm.nbytes, uv.nbytes, tan.nbytes])
+    views = [{"buffer": 0, "byteOffset": int(offs[i]), "byteLength": int(a.nbytes)} for i, a in enumerate((pos, nrm, uv, tan, idx))]
+    acc = [{"bufferView": 0, "componentType": 5126, "count": n, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": n, "type": "VEC3"},
+           {"bufferView": 2, "componentType": 5126, "count": n, "type": "VEC2"}, {"bufferView": 3, "componentType": 5126, "count": n, "type": "VEC4"},
+           {"bufferView": 4, "componentType": 5123, "count": n, "type": "SCALAR"}]
+    def q(axis, ang):
+        a = unit(np.array(axis, np.float64)) * np.sin(ang / 2)
+        return [float(np.float32(a[0])), float(np.float32(a[1])), float(np.float32(a[2])), float(np.float32(np.cos(ang / 2)))]
+    chain = [{"translation": [0.5, -1.25, 2.0], "rotation": q((0, 1, 0), 0.7), "scale": [1.5, 1.5, 1.5]},
+             {"translation": [-0.3, 0.1, 0.2], "rotation": q((1, 2, 3), 1.1), "scale": [0.5, 2.0, 1.25]},
+             {"translation": [0.0, 0.75, -0.5], "rotation": q((-1, 0.5, 0.2), 2.3), "scale": [1.0, 0.8, 1.7]}]
+    m = np.eye(4)
+    m[:3, :3] = np.array([[0.9, -0.2, 0.1], [0.3, 1.1, -0.4], [0.05, 0.2, 0.7]])
+    m[:3, 3] = [1.0, 2.0, -3.0]
+    matrix = [float(np.float32(x)) for x in m.T.reshape(-1)]  # column-major
+    prim = {"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2, "TANGENT": 3}, "indices": 4, "material": 0}
+    nodes = [dict(chain[0], children=[1]), dict(chain[1], children=[2]), dict(chain[2], mesh=0), {"matrix": matrix, "mesh": 1},
+             {"camera": 0, "translation": [0, 0, 5]}]
+    g = {"asset": {"version": "2.0"}, "nodes": nodes, "meshes": [{"primitives": [prim]}, {"primitives": [prim]}],
+         "materials": [{"pbrMetallicRoughness": {"metallicFactor": 0}}], "accessors": acc, "bufferViews": views,
+         "buffers": [{"byteLength": len(blob), "uri": "loader_case.bin"}], "images": [], "textures": [],
+         "cameras": [{"type": "perspective", "perspective": {"yfov": 0.8}}]}
+    os.makedirs(tmpdir, exist_ok=True)
+    open(os.path.join(tmpdir, "loader_case.bin"), "wb").write(blob)
+    path = os.path.join(tmpdir, "loader_case.gltf")
+    json.dump(g, open(path, "w"))
+    flat = lambda c: np.array(c["translation"] + c["rotation"] + c["scale"], np.float32)
+    return path, dict(pos=pos, nrm=nrm, tan=tan, chain=np.stack([flat(c) for c in chain]), matrix=np.array(matrix, np.float32))

@@ -96,6 +96,24 @@ def test_txt_programs_byte_identical(name, flavor):
         assert hashlib.md5(data).hexdigest() == "353a1038e8aaa368d2957931be2cf87d"
 
 
+def test_gltf_loader_transforms_bit_exact(tmp_path):
+    """The product's glTF loader (node TRS chains, `matrix` nodes, inverse-transpose normals, tangents; Figure(v1,v3,v2)
+    corner order) against the reference's own transition.h arithmetic (hw8/src/sceneio.cpp:125-134,247-293)."""
+    import importlib
+    rt = importlib.import_module("raytracing-course-hw_amd")
+    path, lc = pin_cases.loader_case(str(tmp_path))
+    sd = rt.load_gltf(path)
+    gold = np.load(os.path.join(GOLD, "pins_loader_transforms.npz"))
+    n = lc["pos"].shape[0]
+    order = np.arange(n).reshape(-1, 3)[:, [0, 2, 1]].reshape(-1)          # corners (1,3,2) per triangle
+    for k, tag in enumerate(("chain", "matrix")):                            # mesh 0 (node chain) then mesh 1 (matrix node)
+        sl = slice(k * n // 3, (k + 1) * n // 3)
+        assert same(sd.positions[sl].reshape(-1, 3), gold[tag + "_pos"][order]), tag
+        assert same(sd.normals[sl].reshape(-1, 3), gold[tag + "_nrm"][order]), tag
+        assert same(sd.tangents[sl].reshape(-1, 4)[:, :3], gold[tag + "_tan"][order]), tag
+    assert list(sd.camera.position) == [0.0, 0.0, 5.0] and abs(sd.camera.fov_y - 0.8) < 1e-7
+
+
 def test_hw8_sphere_matches_reference_values_recorded_in_survey():
     """SURVEY.md §8(c) records three pixels of the compiled hw8 reference (sphere_emissive, 64x64, 4 spp,
     through the public Scene::getPixel).  They cover the full hw8 getColor, incl. the emissive texture."""

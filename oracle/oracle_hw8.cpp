@@ -11,6 +11,7 @@
 #include <utility>
 #include <atomic>
 #include <omp.h>
+#include <cstdio>
 
 namespace rto {
 
@@ -43,6 +44,7 @@ struct Box { V3 mn, mx; };
 
 struct Counters { uint64_t closest = 0, lightq = 0, boxes = 0, tris = 0; };
 static thread_local Counters tl_cnt;
+static bool g_debug_bruteforce = false;
 
 // ---- primitives.cpp ---------------------------------------------------------------------------
 // primitives.cpp:18-27
@@ -339,7 +341,38 @@ struct FiguresMix {                            // distributions.h:97-166
         float r = total_pdf(cur.right, x, d);
         return l + r;
     }
-    float pdf(V3 x, V3 d) const { tl_cnt.lightq++; return total_pdf(0, x, d) / lights.size(); } // :122-124
+    float pdf(V3 x, V3 d) const { // :122-124
+        tl_cnt.lightq++;
+        float r = total_pdf(0, x, d) / lights.size();
+        if (g_debug_bruteforce) { // diagnostic: lights whose triangle test hits but whose BVH boxes the reference's slab test rejects
+            float brute = 0; int nh = 0;
+            for (const TriLight &tl : lights) { float p = pdf_one(tl, x, d); if (p != 0) nh++; brute += p; }
+            brute /= lights.size();
+            if (brute != r && !(brute != brute && r != r)) {
+                fprintf(stderr, "[oracle] light pdf via BVH %.9g, brute force over all lights %.9g (%d hit)\n", r, brute, nh);
+                for (size_t li = 0; li < lights.size(); li++) {
+                    if (pdf_one(lights[li], x, d) == 0) continue;
+                    uint32_t pos = 0; // walk root -> leaf of light li, report the first rejecting box
+                    for (;;) {
+                        const Node &n = bvh.nodes[pos];
+                        float t; bool inside;
+                        bool ok = aabb_ray(n.aabb, x, d, t, inside);
+                        if (!ok) {
+                            V3 s = 0.5f * (n.aabb.mx - n.aabb.mn), o = x - 0.5f * (n.aabb.mn + n.aabb.mx);
+                            V3 ts1 = (neg1(s) - o) / d, ts2 = (s - o) / d;
+                            fprintf(stderr, "   light %zu pdf %.6g rejected at node %u [%u,%u) box (%.9g %.9g %.9g)-(%.9g %.9g %.9g)\n      o' (%.9g %.9g %.9g) d (%.9g %.9g %.9g) ts1 (%.9g %.9g %.9g) ts2 (%.9g %.9g %.9g)\n",
+                                    li, pdf_one(lights[li], x, d), pos, n.first, n.last, n.aabb.mn.x, n.aabb.mn.y, n.aabb.mn.z, n.aabb.mx.x, n.aabb.mx.y, n.aabb.mx.z,
+                                    o.x, o.y, o.z, d.x, d.y, d.z, ts1.x, ts1.y, ts1.z, ts2.x, ts2.y, ts2.z);
+                            break;
+                        }
+                        if (n.left == 0) break;
+                        pos = (li < bvh.nodes[n.right].first) ? n.left : n.right;
+                    }
+                }
+            }
+        }
+        return r;
+    }
     V3 sample(U01 &u01, rng_t &rng, V3 x) const {                                             // :117-120
         int k = u01(rng) * lights.size();
         return lights[k].sample(u01, rng, x);
@@ -599,6 +632,7 @@ static void *create_common(const rt_scene_desc *d, bool hw7) {
 void *rto_hw8_create(const rt_scene_desc *d) { return create_common(d, false); }
 // hw7 replay mode of the same code (pins the integrator structure)
 void *rto_hw7_create(const rt_scene_desc *d) { return create_common(d, true); }
+void rto_debug_bruteforce_lights(int on) { g_debug_bruteforce = on != 0; }
 void rto_hw8_destroy(void *p) { delete (Scene *)p; }
 
 uint32_t rto_hw8_num_lights(void *p) { return (uint32_t)((Scene *)p)->lightmix.lights.size(); }

@@ -1,0 +1,125 @@
+"""Edge cases of the hw8 path on the GPU, each against the oracle: empty / single-triangle / degenerate geometry, no lights,
+extreme depths and frame sizes, more shards than tiles."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import pin_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _mat(rt, emission=(0, 0, 0), color=(0.8, 0.8, 0.8), metallic=0.0, rough=0.6):
+    m = rt.rt_material()
+    m.base_color, m.emission, m.metallic_factor, m.roughness_factor = color, emission, metallic, rough
+    m.base_color_texture = m.emissive_texture = m.metallic_roughness_texture = m.normal_texture = -1
+    return m
+
+
+def _scene(rt, tris, mats, mat_idx, bg=(0.05, 0.1, 0.2)):
+    tris = np.asarray(tris, np.float32).reshape(-1, 3, 3)
+    n = len(tris)
+    e1, e2 = tris[:, 0] - tris[:, 2], tris[:, 1] - tris[:, 2]
+    nrm = np.cross(e1, e2)
+    ln = np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = np.where(ln > 0, nrm / np.maximum(ln, 1e-30), np.array([0, 0, 1.0]))
+    nrm3 = np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32)
+    tan = np.tile(np.array([1, 0, 0, 1], np.float32), (n, 3, 1))
+    uv = np.zeros((n, 3, 2), np.float32)
+    cam = rt.rt_camera()
+    cam.position, cam.right, cam.up, cam.forward, cam.fov_y = (0, 0, 5), (1, 0, 0), (0, 1, 0), (0, 0, -1), 0.9
+    return rt.SceneData(tris.reshape(n, 9), uv.reshape(n, 6), nrm3.reshape(n, 9), tan.reshape(n, 12), np.asarray(mat_idx, np.uint32), mats, camera=cam, bg=bg)
+
+
+def _check(rt, sd, w, h, spp, depth=0, tag=""):
+    for kernel in ("wavefront", "mega"):
+        import os
+        os.environ["RTAMD_KERNEL"] = kernel
+        scene = rt.Scene(sd)
+        rgb, rgb8, _ = scene.render(w, h, spp, ray_depth=depth)
+        scene.close()
+        ref, ref8, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp, ray_depth=depth)
+        ok = np.array_equal(rgb, ref, equal_nan=True)
+        rmse = float(np.sqrt(np.nanmean((rgb.astype(np.float64) - ref) ** 2)))
+        print(f"{tag}[{kernel}] {w}x{h}x{spp} depth {depth or 6}: bit_exact {ok} rmse {rmse:.2e} nan_px {int(np.isnan(ref).any(axis=2).sum())}")
+        assert np.array_equal(np.isnan(rgb), np.isnan(ref))
+        assert rmse < 1e-3
+        assert (rgb8 != ref8).sum() <= 3
+    os.environ.pop("RTAMD_KERNEL", None)
+
+
+def test_single_triangle_and_one_light(rt):
+    tris = [[[-1, -1, 0], [1, -1, 0], [0, 1, 0]], [[-3, 3, -1], [3, 3, -1], [0, 3, 2]]]
+    sd = _scene(rt, tris, [_mat(rt), _mat(rt, emission=(4, 4, 3))], [0, 1])
+    _check(rt, sd, 40, 24, 8, tag="two triangles")
+    sd1 = _scene(rt, tris[:1], [_mat(rt)], [0])
+    _check(rt, sd1, 17, 9, 3, tag="single triangle, no light")
+
+
+def test_degenerate_triangles(rt):
+    """Zero-area triangles (two equal vertices, a point, three collinear vertices): NaN / inf arithmetic must follow the
+    reference (a NaN barycentric PASSES `u < 0 || v < 0 || u + v > 1`)."""
+    sd0 = pin_cases.random_triangle_scene(n=120, seed=8)
+    pos = sd0.positions.copy().reshape(-1, 3, 3)
+    pos[5, 1] = pos[5, 0]            # two equal vertices
+    pos[9] = pos[9, 0]               # a point
+    pos[13, 2] = (pos[13, 0] + pos[13, 1]) / 2  # collinear
+    mi = sd0.material_index.copy()
+    mi[9] = 3                        # the point is NOT emissive here (see the next test)
+    sd = rt.SceneData(pos.reshape(-1, 9), sd0.texcoords, sd0.normals, sd0.tangents, mi, list(sd0.materials)[:sd0.n_materials], camera=sd0.camera)
+    _check(rt, sd, 48, 36, 6, tag="degenerate")
+
+
+def test_emissive_point_light_known_box_rounding_divergence(rt):
+    """An emissive zero-area triangle makes light sampling aim rays EXACTLY at a vertex, i.e. through the corner of
+    light-BVH boxes.  There the reference's own slab test (6 divisions on a re-centred box, hw8/src/primitives.cpp:29-53)
+    rejects a box by one ulp although the ray hits a triangle inside it, while this implementation's conservative padded
+    test keeps it (known divergences).  The random stream stays in sync; a handful of samples differ."""
+    import os
+    sd0 = pin_cases.random_triangle_scene(n=120, seed=8)
+    pos = sd0.positions.copy().reshape(-1, 3, 3)
+    pos[9] = pos[9, 0]
+    mi = sd0.material_index.copy()
+    mi[9] = 0
+    sd = rt.SceneData(pos.reshape(-1, 9), sd0.texcoords, sd0.normals, sd0.tangents, mi, list(sd0.materials)[:sd0.n_materials], camera=sd0.camera)
+    ref, _, _ = oracle_lib.Hw8Oracle(sd).render(48, 36, 6)
+    imgs = {}
+    for kernel in ("wavefront", "mega"):
+        os.environ["RTAMD_KERNEL"] = kernel
+        scene = rt.Scene(sd)
+        imgs[kernel], _, _ = scene.render(48, 36, 6)
+        scene.close()
+    os.environ.pop("RTAMD_KERNEL", None)
+    assert np.array_equal(imgs["wavefront"], imgs["mega"], equal_nan=True)
+    bad = int((np.abs(imgs["mega"].astype(np.float64) - ref).max(axis=2) > 1e-3).sum())
+    print(f"emissive point light: {bad} of {48 * 36} pixels differ from the oracle")
+    assert bad <= 10
+
+
+@pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 5, 0), (9, 7, 2, 1), (8, 8, 3, 2), (33, 5, 2, 16), (24, 16, 1, 6)])
+def test_sizes_and_depths(rt, sphere_scene, w, h, spp, depth):
+    _check(rt, sphere_scene, w, h, spp, depth, tag="sphere")
+
+
+def test_more_shards_than_tiles(rt, sphere_scene):
+    scene = rt.Scene(sphere_scene)
+    full, full8, _ = scene.render(40, 24, 3)
+    acc = np.zeros_like(full)
+    for r in range(7):  # 3x2 tiles of 16x16 -> shard 6 owns nothing
+        p = rt.make_params(40, 24, 3, shard_index=r, shard_count=7, tile=16)
+        n = rt.lib.rt_output_elems(p)
+        if n == 0:
+            continue
+        buf, _, _ = scene.render(40, 24, 3, shard_index=r, shard_count=7, tile=16)
+        acc += rt.unshard(p, buf)
+    assert np.array_equal(acc, full)
+    scene.close()
+
+
+def test_bad_parameters_are_rejected(rt, sphere_scene):
+    scene = rt.Scene(sphere_scene)
+    for kw in (dict(width=0, height=4, samples=1), dict(width=4, height=4, samples=0), dict(width=4, height=4, samples=1, ray_depth=17),
+               dict(width=4, height=4, samples=1, shard_index=3, shard_count=2), dict(width=4, height=4, samples=1, shard_count=2, tile=12)):
+        with pytest.raises(rt.RtError):
+            scene.render(kw.pop("width"), kw.pop("height"), kw.pop("samples"), **kw)
+    scene.close()

@@ -123,3 +123,25 @@ def test_full_config_1920x1080x256_crops_match_oracle(rt, tmp_path):
         worst = max(worst, rmse)
         assert rmse < RMSE_TOL
     scene.close()
+
+
+@pytest.mark.parametrize("name", ["sphere", "sphere_metallic", "sphere_roughness"])
+def test_reference_sphere_scenes_with_environment_map(rt, tmp_path, name):
+    """The reference's three emitter-less hw8 example scenes (normal map on a dielectric / on a metal, metallic-roughness
+    texture) lit by an environment map, the reference's 6-argument command line (hw8/run.sh:2-5).  The reference ships no
+    environment image, so a procedural equirect PNG is written here and goes through the product's PNG decoder."""
+    import gen_synth_room
+    yy, xx = np.mgrid[0:64, 0:128]
+    env = np.stack([120 + 100 * np.sin(xx / 128 * 2 * np.pi), 140 + 90 * np.cos(yy / 64 * np.pi), 200 - yy * 2], axis=2).clip(0, 255).astype(np.uint8)
+    env[8:14, 30:40] = 255  # a bright patch ("sun")
+    env_path = str(tmp_path / "env.png")
+    gen_synth_room.write_png(env_path, env)
+    sd = rt.load_gltf(os.path.join(ROOT, "tests", "golden", "scenes", "hw8_sphere", name + ".gltf"), environment=env_path)
+    assert sd.environment is not None and np.array_equal(sd.environment, env)
+    scene = rt.Scene(sd)
+    rgb, rgb8, _ = scene.render(80, 80, 8)
+    ref, ref8, _ = oracle_lib.Hw8Oracle(sd).render(80, 80, 8)
+    rmse, bad = _report(f"{name}+env 80x80x8", rgb, ref, rgb8, ref8)
+    assert ref.mean() > 0.02
+    assert rmse < RMSE_TOL and bad <= 6
+    scene.close()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 1
+#define RTAMD_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -48,7 +48,10 @@ typedef enum rt_status {
 /* Which reference integrator the render loop replays. */
 typedef enum rt_integrator {
     RT_INTEGRATOR_HW1 = 1, /* ray caster,  hw1/src/scene.cpp:7-30   */
+    RT_INTEGRATOR_HW2 = 2, /* Whitted-style: point/directional lights, shadow rays, mirror + Fresnel-weighted refraction, hw2/src/scene.cpp:30-84 */
     RT_INTEGRATOR_HW3 = 3, /* first path tracer over analytic primitives, hw3/src/scene.cpp:31-107 */
+    RT_INTEGRATOR_HW4 = 4, /* + cosine / box-light / ellipsoid-light mixture sampling, hw4/src/scene.cpp:10-112, distributions.h */
+    RT_INTEGRATOR_HW5 = 5, /* + TRIANGLE primitives, BVH over non-planes, per-pixel engines, hw5/src/scene.cpp:47-112 */
     RT_INTEGRATOR_HW6 = 6, /* triangles, DIFFUSE/METALLIC/DIELECTRIC, hw6/src/scene.cpp:47-105    */
     RT_INTEGRATOR_HW8 = 8  /* glTF PBR + textures + mixture sampling, hw8/src/scene.cpp:84-165     */
 } rt_integrator;
@@ -79,17 +82,29 @@ typedef struct rt_image {
 } rt_image;
 
 /* Analytic primitive of the .txt scenes (hw1/hw3: hw3/src/include/primitives.h:17-44). */
-typedef enum rt_primitive_type { RT_PRIM_ELLIPSOID = 0, RT_PRIM_PLANE = 1, RT_PRIM_BOX = 2 } rt_primitive_type;
+typedef enum rt_primitive_type { RT_PRIM_ELLIPSOID = 0, RT_PRIM_PLANE = 1, RT_PRIM_BOX = 2, RT_PRIM_TRIANGLE = 3 } rt_primitive_type;
 typedef struct rt_primitive {
     int32_t type;        /* rt_primitive_type */
-    float data[3];       /* radii | plane normal | box half-sizes */
+    float data[3];       /* radii | plane normal | box half-sizes | triangle: Figure::data (third vertex of the TRIANGLE line) */
     float position[3];
     float rotation[4];   /* quaternion x,y,z,w exactly as parsed (may be non-unit) */
     float color[3];
     float emission[3];
     int32_t kind;        /* rt_material_kind */
     float ior;
+    float data2[3];      /* TRIANGLE (hw5/src/sceneio.cpp:27-29): second vertex of the line */
+    float data3[3];      /* TRIANGLE: first vertex of the line (the BVH / light code's "a") */
 } rt_primitive;
+
+/* hw2 light source (hw2/src/include/light_source.h:15-30). */
+typedef enum rt_light_type { RT_LIGHT_POINT = 0, RT_LIGHT_DIRECTIONAL = 1 } rt_light_type;
+typedef struct rt_light {
+    int32_t type;         /* rt_light_type */
+    float intensity[3];
+    float position[3];    /* point light */
+    float attenuation[3]; /* point light: c0 + c1*r + c2*r^2 */
+    float direction[3];   /* directional light, as parsed (normalised per query like the reference) */
+} rt_light;
 
 typedef struct rt_camera {
     float position[3], right[3], up[3], forward[3];
@@ -120,6 +135,9 @@ typedef struct rt_scene_desc {
     const rt_primitive *primitives;
     rt_camera camera;
     float bg_color[3];
+    uint32_t n_lights;               /* HW2 only */
+    const rt_light *lights;
+    float ambient_light[3];          /* HW2 only (AMBIENT_LIGHT) */
 } rt_scene_desc;
 
 #define RT_FLAG_OUT_DEVICE 1u /* out_rgb_linear / out_rgb8 are device pointers on the scene's GPU */
@@ -188,7 +206,8 @@ typedef struct rt_host_scene rt_host_scene; /* owns the arrays a desc points int
 /* glTF 2.0 subset loader, float-for-float the reference's (hw8/src/sceneio.cpp:348-372).
  * flavor: RT_INTEGRATOR_HW6 or RT_INTEGRATOR_HW8 (material interpretation differs). */
 int rt_load_gltf(const char *path, int flavor, rt_host_scene **out);
-/* .txt scene loader (hw1/hw3 grammar, hw3/src/sceneio.cpp:62-107). Fills width/height/samples/ray_depth. */
+/* .txt scene loader (flavor RT_INTEGRATOR_HW1..HW5 picks that snapshot's grammar: hw1/src/sceneio.cpp:8-97,
+ * hw2/src/sceneio.cpp:8-147, hw3/src/sceneio.cpp:8-107, hw5/src/sceneio.cpp:8-101). Fills width/height/samples/ray_depth. */
 int rt_load_txt(const char *path, int flavor, rt_host_scene **out,
                 int32_t *width, int32_t *height, int32_t *samples, int32_t *ray_depth);
 int rt_host_scene_set_environment(rt_host_scene *hs, const char *image_path);

@@ -135,8 +135,8 @@ struct Scene3 {
         }
     }
     // hw3/src/scene.cpp:99-107
-    void camera_ray(float x, float y, V3 &o, V3 &d) const {
-        float tanFovX = std::tan((double)(fovX / 2));
+    void camera_ray(float x, float y, V3 &o, V3 &d, bool float_tan = false) const {
+        float tanFovX = float_tan ? tanf(fovX / 2) : (float)std::tan((double)(fovX / 2)); // hw1: <math.h> => tanf
         float tanFovY = tanFovX * height / width;
         float nx = tanFovX * (2 * (x + 0.5) / width - 1);
         float ny = tanFovY * (2 * (y + 0.5) / height - 1);
@@ -168,8 +168,8 @@ static bool prim_ray1(const Prim &f, V3 o, V3 d, float &t) {
         float a = len2(td / r);
         float dd = b * b - 4 * a * c;
         if (dd <= 0) return false;
-        float x1 = (-b - std::sqrt((double)dd)) / (2 * a);
-        float x2 = (-b + std::sqrt((double)dd)) / (2 * a);
+        float x1 = (-b - sqrtf(dd)) / (2 * a);   // hw1 includes <math.h>: sqrt(float) is the float overload (see oracle_hw2.cpp)
+        float x2 = (-b + sqrtf(dd)) / (2 * a);
         if (x1 > x2) std::swap(x1, x2);
         if (x2 < 0) return false;
         t = x1 < 0 ? x2 : x1;
@@ -219,7 +219,7 @@ int rto_hw1_render(void *p, int width, int height, float *out_rgb, uint8_t *out8
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
             V3 o, d;
-            s->camera_ray((float)x, (float)y, o, d); // hw1/src/scene.cpp:22-30 takes ints; (x + 0.5) is the same double either way
+            s->camera_ray((float)x, (float)y, o, d, true); // hw1/src/scene.cpp:22-30 takes ints; (x + 0.5) is the same double either way
             V3 ans = s->bg;
             float best = -1;
             for (const Prim &f : s->figs) {

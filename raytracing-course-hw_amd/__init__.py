@@ -15,7 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtamd.so")
 
-RT_INTEGRATOR_HW1, RT_INTEGRATOR_HW3, RT_INTEGRATOR_HW6, RT_INTEGRATOR_HW8 = 1, 3, 6, 8
+RT_INTEGRATOR_HW1, RT_INTEGRATOR_HW2, RT_INTEGRATOR_HW3, RT_INTEGRATOR_HW4, RT_INTEGRATOR_HW5 = 1, 2, 3, 4, 5
+RT_INTEGRATOR_HW6, RT_INTEGRATOR_HW8 = 6, 8
 RT_FLAG_OUT_DEVICE, RT_FLAG_COUNTERS = 1, 2
 RT_OK = 0
 RT_ERR_NO_DEVICE = -2
@@ -40,7 +41,13 @@ class rt_image(C.Structure):
 
 class rt_primitive(C.Structure):
     _fields_ = [("type", C.c_int32), ("data", C.c_float * 3), ("position", C.c_float * 3), ("rotation", C.c_float * 4),
-                ("color", C.c_float * 3), ("emission", C.c_float * 3), ("kind", C.c_int32), ("ior", C.c_float)]
+                ("color", C.c_float * 3), ("emission", C.c_float * 3), ("kind", C.c_int32), ("ior", C.c_float),
+                ("data2", C.c_float * 3), ("data3", C.c_float * 3)]
+
+
+class rt_light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("intensity", C.c_float * 3), ("position", C.c_float * 3),
+                ("attenuation", C.c_float * 3), ("direction", C.c_float * 3)]
 
 
 class rt_camera(C.Structure):
@@ -58,7 +65,8 @@ class rt_scene_desc(C.Structure):
                 ("n_images", C.c_uint32), ("images", C.POINTER(rt_image)),
                 ("environment_map", C.POINTER(rt_image)),
                 ("n_primitives", C.c_uint32), ("primitives", C.POINTER(rt_primitive)),
-                ("camera", rt_camera), ("bg_color", C.c_float * 3)]
+                ("camera", rt_camera), ("bg_color", C.c_float * 3),
+                ("n_lights", C.c_uint32), ("lights", C.POINTER(rt_light)), ("ambient_light", C.c_float * 3)]
 
 
 class rt_render_params(C.Structure):
@@ -127,7 +135,7 @@ class SceneData:
     """Scene arrays in LOAD order as numpy (owns its memory) + an rt_scene_desc pointing at them."""
 
     def __init__(self, positions, texcoords, normals, tangents, material_index, materials, texture_source=(), images=(),
-                 camera=None, bg=(0, 0, 0), environment=None, primitives=None):
+                 camera=None, bg=(0, 0, 0), environment=None, primitives=None, lights=None, ambient=(0, 0, 0)):
         f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
         self.positions = f32(positions if positions is not None else np.zeros(0, np.float32)).reshape(-1, 9)
         n = self.positions.shape[0]
@@ -143,6 +151,8 @@ class SceneData:
         self.bg = tuple(float(x) for x in bg)
         self.environment = None if environment is None else np.ascontiguousarray(environment, dtype=np.uint8)
         self.primitives = primitives
+        self.lights = lights
+        self.ambient = tuple(float(x) for x in ambient)
         self._build_desc()
 
     def _build_desc(self):
@@ -173,6 +183,11 @@ class SceneData:
             d.primitives = self._prims
         d.camera = self.camera
         d.bg_color = (C.c_float * 3)(*self.bg)
+        if self.lights is not None and len(self.lights):
+            self._lights = (rt_light * len(self.lights))(*self.lights)
+            d.n_lights = len(self.lights)
+            d.lights = self._lights
+        d.ambient_light = (C.c_float * 3)(*self.ambient)
         self.desc = d
 
     @staticmethod
@@ -191,9 +206,11 @@ class SceneData:
             env = np.ctypeslib.as_array(im.rgb, shape=(im.height, im.width, 3)).copy()
         tsrc = np.ctypeslib.as_array(desc.texture_source, shape=(desc.n_textures,)).copy() if desc.n_textures else ()
         prims = [rt_primitive.from_buffer_copy(desc.primitives[i]) for i in range(desc.n_primitives)]
+        lights = [rt_light.from_buffer_copy(desc.lights[i]) for i in range(desc.n_lights)]
         return SceneData(arr(desc.positions, 9), arr(desc.texcoords, 6), arr(desc.normals, 9), arr(desc.tangents, 12),
                          np.ctypeslib.as_array(desc.material_index, shape=(n,)).copy() if n else np.zeros(0, np.uint32),
-                         mats, tsrc, images, rt_camera.from_buffer_copy(desc.camera), tuple(desc.bg_color), env, prims)
+                         mats, tsrc, images, rt_camera.from_buffer_copy(desc.camera), tuple(desc.bg_color), env, prims, lights,
+                         tuple(desc.ambient_light))
 
 
 def load_gltf(path, flavor=RT_INTEGRATOR_HW8, environment=None):
@@ -209,7 +226,7 @@ def load_gltf(path, flavor=RT_INTEGRATOR_HW8, environment=None):
 
 
 def load_txt(path, flavor=RT_INTEGRATOR_HW3):
-    """Load a .txt scene (hw1/hw3 grammar). Returns (SceneData, width, height, samples, ray_depth)."""
+    """Load a .txt scene (grammar of snapshot hw1..hw5 by flavor). Returns (SceneData, width, height, samples, ray_depth)."""
     hs = C.c_void_p()
     w, h, s, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
     _check(lib.rt_load_txt(os.fsencode(path), flavor, C.byref(hs), C.byref(w), C.byref(h), C.byref(s), C.byref(d)))

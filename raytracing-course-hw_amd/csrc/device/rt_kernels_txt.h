@@ -20,12 +20,24 @@ struct GpuPrim {              // 80 bytes
 };
 static_assert(sizeof(GpuPrim) == 80, "GpuPrim must be 80 bytes");
 
+struct GpuLight {             // 64 bytes, hw2 only
+    float intensity[3]; int32_t type;
+    float position[3]; float pad0;
+    float attenuation[3]; float pad1;
+    float direction[3]; float pad2;
+};
+static_assert(sizeof(GpuLight) == 64, "GpuLight must be 64 bytes");
+
 struct SceneViewTxt {
     const GpuPrim *prims;
     uint32_t n_prims;
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float bg[3];
     float tan_fov_x;          // (float)tan((double)(fovX / 2)), hw3/src/scene.cpp:100
+    float tan_fov_x_f;        // tanf(fovX / 2): hw1/hw2 compile against <math.h>, where tan(float) is the float overload
+    const GpuLight *lights;   // hw2
+    uint32_t n_lights;
+    float ambient[3];         // hw2 AMBIENT_LIGHT
 };
 
 namespace dev {
@@ -44,13 +56,22 @@ RT_DEV PrimRegs load_prim(const GpuPrim *p) {
 }
 RT_DEV F3 div3(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 
-// hw3/src/primitives.cpp:28-47
+// hw3/src/primitives.cpp:28-47.  FLOAT_ROOTS: the hw1/hw2 form (hw2/src/primitives.cpp:37-56), where sqrt(d) is the
+// float overload and the whole quotient stays in float; hw3+ (<cmath>) promote to double and narrow once.
+template <bool FLOAT_ROOTS>
 RT_DEV bool smallest_root(float a, float b, float c, float &t, bool &inside) {
     float d = b * b - 4 * a * c;
     if (d <= 0) return false;
-    double sd = sqrt((double)d), den = (double)(2 * a);
-    float x1 = (float)(((double)(-b) - sd) / den);
-    float x2 = (float)(((double)(-b) + sd) / den);
+    float x1, x2;
+    if (FLOAT_ROOTS) {
+        float sd = sqrtf(d);
+        x1 = (-b - sd) / (2 * a);
+        x2 = (-b + sd) / (2 * a);
+    } else {
+        double sd = sqrt((double)d), den = (double)(2 * a);
+        x1 = (float)(((double)(-b) - sd) / den);
+        x2 = (float)(((double)(-b) + sd) / den);
+    }
     if (x1 > x2) { float tmp = x1; x1 = x2; x2 = tmp; }
     if (x2 < 0) return false;
     if (x1 < 0) { t = x2; inside = true; } else { t = x1; inside = false; }
@@ -70,7 +91,8 @@ RT_DEV bool box_slabs(F3 s, F3 o, F3 d, float &t, bool &inside) {
 
 // Figure::intersect of hw3 (hw3/src/primitives.cpp:8-123): object-space ray via q*p*conj(q) with the quaternion
 // exactly as parsed (it may be non-unit), normal rotated back and normalised.
-RT_DEV bool prim_hit3(const PrimRegs &P, F3 o, F3 d, float &t, F3 &norma, bool &inside) {
+template <bool FLOAT_ROOTS>
+RT_DEV bool prim_hit(const PrimRegs &P, F3 o, F3 d, float &t, F3 &norma, bool &inside) {
     F3 to = qtransform(P.rot, o - P.position), td = qtransform(P.rot, d);
     F3 n;
     if (P.type == RT_PRIM_ELLIPSOID) {
@@ -79,7 +101,7 @@ RT_DEV bool prim_hit3(const PrimRegs &P, F3 o, F3 d, float &t, F3 &norma, bool &
         float c = len2(orr) - 1;
         float b = 2.0f * dot(orr, drr);
         float a = len2(drr);
-        if (!smallest_root(a, b, c, t, inside)) return false;
+        if (!smallest_root<FLOAT_ROOTS>(a, b, c, t, inside)) return false;
         F3 point = to + t * td;
         n = div3(point, r * r);
         if (inside) n = neg(n);
@@ -106,9 +128,11 @@ RT_DEV bool prim_hit3(const PrimRegs &P, F3 o, F3 d, float &t, F3 &norma, bool &
     return true;
 }
 
+RT_DEV bool prim_hit3(const PrimRegs &P, F3 o, F3 d, float &t, F3 &norma, bool &inside) { return prim_hit<false>(P, o, d, t, norma, inside); }
+
 // hw3/src/scene.cpp:99-107 (shared by hw1/src/scene.cpp:22-30): pixel centre +0.5 on top of the jitter, FOV_X based.
-RT_DEV void camera_ray_txt(const SceneViewTxt &S, float tan_fov_y, int width, int height, float x, float y, F3 &o, F3 &d) {
-    float nx = (float)((double)S.tan_fov_x * (2 * ((double)x + 0.5) / (double)width - 1));
+RT_DEV void camera_ray_txt(const SceneViewTxt &S, float tan_fov_x, float tan_fov_y, int width, int height, float x, float y, F3 &o, F3 &d) {
+    float nx = (float)((double)tan_fov_x * (2 * ((double)x + 0.5) / (double)width - 1));
     float ny = (float)((double)tan_fov_y * (2 * ((double)y + 0.5) / (double)height - 1));
     o = f3(S.cam_pos);
     d = nx * f3(S.cam_right) - ny * f3(S.cam_up) + f3(S.cam_fwd);
@@ -120,7 +144,7 @@ __global__ __launch_bounds__(256) void render_hw1_kernel(SceneViewTxt S, int wid
     if (i >= width * height) return;
     int x = i % width, y = i / width;
     F3 o, d;
-    camera_ray_txt(S, tan_fov_y, width, height, (float)x, (float)y, o, d);
+    camera_ray_txt(S, S.tan_fov_x_f, tan_fov_y, width, height, (float)x, (float)y, o, d);
     F3 ans = f3(S.bg);
     float best = -1;
     for (uint32_t k = 0; k < S.n_prims; k++) {                         // hw1/src/scene.cpp:10-18
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(256) void render_hw1_kernel(SceneViewTxt S, int wid
             float b = dot(2 * orr, drr);
             float a = len2(drr);
             bool inside;
-            hit = smallest_root(a, b, c, t, inside);
+            hit = smallest_root<true>(a, b, c, t, inside);           // hw1/src/primitives.cpp:33-52, float sqrt
         } else if (P.type == RT_PRIM_PLANE) {                          // :64-70 (normal not normalised in hw1)
             t = -dot(to, P.data) / dot(td, P.data);
             hit = t > 0;
@@ -243,7 +267,7 @@ __global__ __launch_bounds__(64) void render_hw3_kernel(SceneViewTxt S, RenderVi
                 float nx = (float)x + rng_u01(rng);
                 float ny = (float)y + rng_u01(rng);
                 F3 o, d;
-                camera_ray_txt(S, tan_fov_y, R.width, R.height, nx, ny, o, d);
+                camera_ray_txt(S, S.tan_fov_x, tan_fov_y, R.width, R.height, nx, ny, o, d);
                 color = color + trace_tree3(S, R.ray_depth, rng, o, d);
             }
             px = R.inv_samples * color;

@@ -16,6 +16,8 @@ struct rt_host_scene {
     rt_image env{0, 0, nullptr};
     bool has_env = false;
     std::vector<rt_primitive> primitives;
+    std::vector<rt_light> lights;
+    float ambient[3] = {0, 0, 0};
     rt_camera camera{};
     float bg[3] = {0, 0, 0};
     rt_scene_desc desc{};
@@ -42,6 +44,9 @@ struct rt_host_scene {
         desc.primitives = primitives.data();
         desc.camera = camera;
         desc.bg_color[0] = bg[0]; desc.bg_color[1] = bg[1]; desc.bg_color[2] = bg[2];
+        desc.n_lights = (uint32_t)lights.size();
+        desc.lights = lights.data();
+        desc.ambient_light[0] = ambient[0]; desc.ambient_light[1] = ambient[1]; desc.ambient_light[2] = ambient[2];
     }
 };
 

@@ -18,6 +18,7 @@
 #include "device/rt_wavefront.h"
 #include "device/rt_kernels_hw6.h"
 #include "device/rt_kernels_txt.h"
+#include "device/rt_kernels_hw2.h"
 #include <cstdlib>
 
 namespace rtamd {
@@ -138,6 +139,19 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                 V.bg[k] = desc->bg_color[k];
             }
             V.tan_fov_x = (float)std::tan((double)(desc->camera.fov_x / 2)); // hw3/src/scene.cpp:100
+            V.tan_fov_x_f = tanf(desc->camera.fov_x / 2);                    // hw1/src/scene.cpp:23, hw2/src/scene.cpp:91 (<math.h>: float overload)
+            std::vector<GpuLight> lights(desc->n_lights);
+            for (uint32_t i = 0; i < desc->n_lights; i++) {
+                const rt_light &L = desc->lights[i];
+                GpuLight &g = lights[i];
+                memset(&g, 0, sizeof g);
+                if (L.type != RT_LIGHT_POINT && L.type != RT_LIGHT_DIRECTIONAL) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: bad light type");
+                g.type = L.type;
+                for (int k = 0; k < 3; k++) { g.intensity[k] = L.intensity[k]; g.position[k] = L.position[k]; g.attenuation[k] = L.attenuation[k]; g.direction[k] = L.direction[k]; }
+            }
+            V.n_lights = desc->n_lights;
+            if (desc->n_lights) { V.lights = upload(lights, bytes); s->allocations.push_back((void *)V.lights); }
+            for (int k = 0; k < 3; k++) V.ambient[k] = desc->ambient_light[k];
             s->flavor = RT_INTEGRATOR_HW3;
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
@@ -351,10 +365,11 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
 int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
-    if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6 && p->integrator != RT_INTEGRATOR_HW3 && p->integrator != RT_INTEGRATOR_HW1)
+    if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6 && p->integrator != RT_INTEGRATOR_HW3 && p->integrator != RT_INTEGRATOR_HW1 &&
+        p->integrator != RT_INTEGRATOR_HW2)
         return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown integrator");
     const bool txt_scene = scene->flavor == RT_INTEGRATOR_HW3;
-    const bool txt_integrator = p->integrator == RT_INTEGRATOR_HW3 || p->integrator == RT_INTEGRATOR_HW1;
+    const bool txt_integrator = p->integrator >= RT_INTEGRATOR_HW1 && p->integrator <= RT_INTEGRATOR_HW5;
     if (txt_scene != txt_integrator || (!txt_scene && p->integrator != scene->flavor))
         return fail(RT_ERR_INVALID_ARG, "rt_render: this scene was prepared for integrator " + std::to_string(scene->flavor) +
                                             " (hw6 scenes carry no vertex normals, hw8 scenes do)");
@@ -396,9 +411,11 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
         if (scene->info.bvh_depth > WF_STACK || scene->info.light_bvh_depth > WF_STACK || scene->info.n_triangles >= 0x40000000u) use_wavefront = false;
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
-        if (txt_scene && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
+        if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
+        if (p->integrator == RT_INTEGRATOR_HW2 && R.ray_depth > RT2_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw2 ray_depth above 16");
         if (p->integrator == RT_INTEGRATOR_HW1 && R.shard_count > 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: the hw1 caster renders unsharded frames only");
-        const float txt_tan_fov_y = scene->viewt.tan_fov_x * R.height / R.width; // hw3/src/scene.cpp:101
+        const bool float_tan = p->integrator == RT_INTEGRATOR_HW1 || p->integrator == RT_INTEGRATOR_HW2;
+        const float txt_tan_fov_y = (float_tan ? scene->viewt.tan_fov_x_f : scene->viewt.tan_fov_x) * R.height / R.width; // hw3/src/scene.cpp:101
         if (scene->flavor == RT_INTEGRATOR_HW6 && R.ray_depth > RT6_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw6 ray_depth above 8");
         uint32_t launches = 0;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
@@ -409,6 +426,10 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             } else if (p->integrator == RT_INTEGRATOR_HW1) {
                 uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
                 hipLaunchKernelGGL(dev::render_hw1_kernel, dim3((npx + 255) / 256), dim3(256), 0, stream, scene->viewt, R.width, R.height, txt_tan_fov_y, d_rgb, d_rgb8);
+                HIP_CHECK(hipGetLastError());
+                launches = 1;
+            } else if (p->integrator == RT_INTEGRATOR_HW2) {
+                hipLaunchKernelGGL(dev::render_hw2_kernel, dim3(blocks), dim3(64), 0, stream, scene->viewt, R, txt_tan_fov_y, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
             } else if (txt_scene) {

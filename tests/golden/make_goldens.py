@@ -75,6 +75,21 @@ def main():
             out[name + "_ppm"] = np.frombuffer(data, np.uint8)
         print(name, hashlib.md5(data).hexdigest(), len(data))
     np.savez_compressed(os.path.join(HERE, "pins_txt_programs.npz"), **out)
+    # hw2: float radiance through the reference's own loader + Scene::getPixel, and the program's PPM md5
+    out = {}
+    for name in pin_cases.HW2_CASES:
+        path = os.path.join(txt, name + ".txt")
+        out[name + "_rgb"] = oracle_lib.RefTxt(2, path).render()
+        with tempfile.TemporaryDirectory() as td:
+            ppm = os.path.join(td, "o.ppm")
+            subprocess.run([oracle_lib.ref_path("hw2_main"), path, ppm], check=True, stderr=subprocess.DEVNULL)
+            out[name + "_md5"] = np.frombuffer(hashlib.md5(open(ppm, "rb").read()).hexdigest().encode(), np.uint8)
+        print(name, out[name + "_rgb"].shape, float(out[name + "_rgb"].mean()), bytes(out[name + "_md5"]).decode())
+    with tempfile.TemporaryDirectory() as td:
+        ppm = os.path.join(td, "o.ppm")
+        subprocess.run([oracle_lib.ref_path("hw2_main"), os.path.join(txt, "hw2_sample.txt"), ppm], check=True, stderr=subprocess.DEVNULL)
+        out["hw2_sample_md5"] = np.frombuffer(hashlib.md5(open(ppm, "rb").read()).hexdigest().encode(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "pins_hw2_render.npz"), **out)
 
 
 if __name__ == "__main__":

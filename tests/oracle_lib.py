@@ -18,7 +18,7 @@ class Counters(C.Structure):
 
 def _build():
     so = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
-    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_hw8.cpp", "oracle_hw6.cpp", "oracle_txt.cpp", "oracle_common.h")]
+    src = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "_build/liboracle.so"])
     return so
@@ -296,3 +296,67 @@ class TxtOracle:
         rgb8 = np.zeros((h, w, 3), np.uint8)
         lib().rto_hw3_render(self._h, width, height, samples, ray_depth, 1 if per_pixel_seed else 0, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
         return rgb, rgb8
+
+
+class Hw2Oracle:
+    """CPU restatement of the hw2 Whitted-style tracer (oracle/oracle_hw2.cpp); deterministic."""
+
+    def __init__(self, scene_data):
+        self.data = scene_data
+        L = lib()
+        L.rto_hw2_create.restype = C.c_void_p
+        L.rto_hw2_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.rto_hw2_destroy.argtypes = [C.c_void_p]
+        L.rto_hw2_render.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int]
+        self._h = L.rto_hw2_create(C.byref(scene_data.desc))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rto_hw2_destroy(self._h)
+            self._h = None
+
+    def render(self, width, height, ray_depth, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        lib().rto_hw2_render(self._h, width, height, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
+        return rgb, rgb8
+
+
+class RefTxt:
+    """The reference's own hw2 / hw4 / hw5 loader + Scene::getPixel (oracle/_ref/libref_hw{2,4,5}.so, float radiance)."""
+
+    def __init__(self, hw, path):
+        self.L = C.CDLL(ref_path(f"libref_hw{hw}.so"))
+        self.L.ref_txt_load.restype = C.c_void_p
+        self.L.ref_txt_load.argtypes = [C.c_char_p]
+        self.L.ref_txt_free.argtypes = [C.c_void_p]
+        self.L.ref_txt_params.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        self.L.ref_txt_render.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+        self.L.ref_txt_tonemap.argtypes = [C.c_void_p, C.c_void_p]
+        self._h = self.L.ref_txt_load(os.fsencode(path))
+        assert self._h, path
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.L.ref_txt_free(self._h)
+            self._h = None
+
+    def params(self, width=0, height=0, samples=0, ray_depth=0):
+        v = [C.c_int(width), C.c_int(height), C.c_int(samples), C.c_int(ray_depth)]
+        self.L.ref_txt_params(self._h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def render(self, rect=None):
+        w, h, _, _ = self.params()
+        x0, y0, rw, rh = rect if rect else (0, 0, w, h)
+        rgb = np.zeros((rh, rw, 3), np.float32)
+        self.L.ref_txt_render(self._h, x0, y0, rw, rh, rgb.ctypes.data)
+        return rgb
+
+    def tonemap(self, rgb):
+        flat = np.ascontiguousarray(rgb, np.float32).reshape(-1, 3)
+        out = np.zeros((flat.shape[0], 3), np.uint8)
+        for i in range(flat.shape[0]):
+            self.L.ref_txt_tonemap(flat[i].ctypes.data, out[i].ctypes.data)
+        return out.reshape(rgb.shape)

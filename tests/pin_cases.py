@@ -175,3 +175,7 @@ def loader_case(tmpdir):
     json.dump(g, open(path, "w"))
     flat = lambda c: np.array(c["translation"] + c["rotation"] + c["scale"], np.float32)
     return path, dict(pos=pos, nrm=nrm, tan=tan, chain=np.stack([flat(c) for c in chain]), matrix=np.array(matrix, np.float32))
+
+
+# hw2 scenes pinned through the reference's own loader + getPixel (float radiance) and program (PPM md5).
+HW2_CASES = ("hw2_sample_166x128", "hw2_glass_stack")

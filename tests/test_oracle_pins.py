@@ -96,6 +96,22 @@ def test_txt_programs_byte_identical(name, flavor):
         assert hashlib.md5(data).hexdigest() == "353a1038e8aaa368d2957931be2cf87d"
 
 
+@pytest.mark.parametrize("name", pin_cases.HW2_CASES)
+def test_hw2_whole_tracer_bit_exact(name):
+    """hw2 (deterministic Whitted tracer): this repo's .txt loader + oracle/oracle_hw2.cpp against the float radiance the
+    reference's own loader + Scene::getPixel produced (oracle/ref/ref_txt_scene.cpp), bit for bit, and against the md5 of
+    the PPM the unmodified hw2 program wrote."""
+    import hashlib
+    import importlib
+    rt = importlib.import_module("raytracing-course-hw_amd")
+    gold = np.load(os.path.join(GOLD, "pins_hw2_render.npz"))
+    sd, w, h, _, depth = rt.load_txt(os.path.join(GOLD, "scenes", "txt", name + ".txt"), rt.RT_INTEGRATOR_HW2)
+    rgb, rgb8 = oracle_lib.Hw2Oracle(sd).render(w, h, depth)
+    assert gold[name + "_rgb"].mean() > 0.01
+    assert same(rgb, gold[name + "_rgb"]), f"{name}: linear radiance differs from the reference"
+    assert hashlib.md5(_ppm(w, h, rgb8)).hexdigest() == bytes(gold[name + "_md5"]).decode()
+
+
 def test_gltf_loader_transforms_bit_exact(tmp_path):
     """The product's glTF loader (node TRS chains, `matrix` nodes, inverse-transpose normals, tangents; Figure(v1,v3,v2)
     corner order) against the reference's own transition.h arithmetic (hw8/src/sceneio.cpp:125-134,247-293)."""

@@ -38,6 +38,8 @@ struct SceneViewTxt {
     const GpuLight *lights;   // hw2
     uint32_t n_lights;
     float ambient[3];         // hw2 AMBIENT_LIGHT
+    const uint32_t *light_prims; // hw4: emissive BOX / ELLIPSOID primitives in figure order (hw4/src/scene.cpp:12-21)
+    uint32_t n_light_prims;
 };
 
 namespace dev {
@@ -91,7 +93,8 @@ RT_DEV bool box_slabs(F3 s, F3 o, F3 d, float &t, bool &inside) {
 
 // Figure::intersect of hw3 (hw3/src/primitives.cpp:8-123): object-space ray via q*p*conj(q) with the quaternion
 // exactly as parsed (it may be non-unit), normal rotated back and normalised.
-template <bool FLOAT_ROOTS>
+// PLANE_TMAX: hw4+ reject plane hits at t >= T_MAX = 1e4 (hw4/src/primitives.cpp:8,74).
+template <bool FLOAT_ROOTS, bool PLANE_TMAX = false>
 RT_DEV bool prim_hit(const PrimRegs &P, F3 o, F3 d, float &t, F3 &norma, bool &inside) {
     F3 to = qtransform(P.rot, o - P.position), td = qtransform(P.rot, d);
     F3 n;
@@ -110,7 +113,7 @@ RT_DEV bool prim_hit(const PrimRegs &P, F3 o, F3 d, float &t, F3 &norma, bool &i
         F3 pn = P.data;
         float dn = dot(td, pn);
         t = -dot(to, pn) / dn;
-        if (!(t > 0)) return false;
+        if (!(t > 0) || (PLANE_TMAX && !(t < 1e4f))) return false;
         inside = dn > 0;
         n = inside ? neg(pn) : pn;
     } else {

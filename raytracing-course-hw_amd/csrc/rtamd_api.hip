@@ -19,6 +19,7 @@
 #include "device/rt_kernels_hw6.h"
 #include "device/rt_kernels_txt.h"
 #include "device/rt_kernels_hw2.h"
+#include "device/rt_kernels_hw4.h"
 #include <cstdlib>
 
 namespace rtamd {
@@ -152,6 +153,13 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             V.n_lights = desc->n_lights;
             if (desc->n_lights) { V.lights = upload(lights, bytes); s->allocations.push_back((void *)V.lights); }
             for (int k = 0; k < 3; k++) V.ambient[k] = desc->ambient_light[k];
+            std::vector<uint32_t> light_prims; // hw4/src/scene.cpp:12-21
+            for (uint32_t i = 0; i < desc->n_primitives; i++) {
+                const rt_primitive &p = desc->primitives[i];
+                if ((p.emission[0] > 0 || p.emission[1] > 0 || p.emission[2] > 0) && (p.type == RT_PRIM_BOX || p.type == RT_PRIM_ELLIPSOID)) light_prims.push_back(i);
+            }
+            V.n_light_prims = (uint32_t)light_prims.size();
+            if (!light_prims.empty()) { V.light_prims = upload(light_prims, bytes); s->allocations.push_back((void *)V.light_prims); }
             s->flavor = RT_INTEGRATOR_HW3;
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
@@ -366,7 +374,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
     if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6 && p->integrator != RT_INTEGRATOR_HW3 && p->integrator != RT_INTEGRATOR_HW1 &&
-        p->integrator != RT_INTEGRATOR_HW2)
+        p->integrator != RT_INTEGRATOR_HW2 && p->integrator != RT_INTEGRATOR_HW4)
         return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown integrator");
     const bool txt_scene = scene->flavor == RT_INTEGRATOR_HW3;
     const bool txt_integrator = p->integrator >= RT_INTEGRATOR_HW1 && p->integrator <= RT_INTEGRATOR_HW5;
@@ -412,6 +420,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (scene->info.bvh_depth > WF_STACK || scene->info.light_bvh_depth > WF_STACK || scene->info.n_triangles >= 0x40000000u) use_wavefront = false;
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
+        if (p->integrator == RT_INTEGRATOR_HW4 && R.ray_depth > RT4_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw4 ray_depth above 8");
+        if (p->integrator == RT_INTEGRATOR_HW4 && scene->viewt.n_light_prims > RT4_MAX_LIGHTS) return fail(RT_ERR_LIMIT, "rt_render: hw4 supports at most 32 emissive box/ellipsoid lights");
         if (p->integrator == RT_INTEGRATOR_HW2 && R.ray_depth > RT2_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw2 ray_depth above 16");
         if (p->integrator == RT_INTEGRATOR_HW1 && R.shard_count > 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: the hw1 caster renders unsharded frames only");
         const bool float_tan = p->integrator == RT_INTEGRATOR_HW1 || p->integrator == RT_INTEGRATOR_HW2;
@@ -426,6 +436,10 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             } else if (p->integrator == RT_INTEGRATOR_HW1) {
                 uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
                 hipLaunchKernelGGL(dev::render_hw1_kernel, dim3((npx + 255) / 256), dim3(256), 0, stream, scene->viewt, R.width, R.height, txt_tan_fov_y, d_rgb, d_rgb8);
+                HIP_CHECK(hipGetLastError());
+                launches = 1;
+            } else if (p->integrator == RT_INTEGRATOR_HW4) {
+                hipLaunchKernelGGL(dev::render_hw4_kernel, dim3(blocks), dim3(64), 0, stream, scene->viewt, R, txt_tan_fov_y, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
             } else if (p->integrator == RT_INTEGRATOR_HW2) {

@@ -90,6 +90,12 @@ def main():
         subprocess.run([oracle_lib.ref_path("hw2_main"), os.path.join(txt, "hw2_sample.txt"), ppm], check=True, stderr=subprocess.DEVNULL)
         out["hw2_sample_md5"] = np.frombuffer(hashlib.md5(open(ppm, "rb").read()).hexdigest().encode(), np.uint8)
     np.savez_compressed(os.path.join(HERE, "pins_hw2_render.npz"), **out)
+    # hw4: float radiance of the reference's sequential stream (fresh process per scene: the engine is a file-static)
+    out = {}
+    for name in pin_cases.HW4_CASES:
+        out[name + "_rgb"] = oracle_lib.ref_txt_render_fresh(4, os.path.join(txt, name + ".txt"))
+        print(name, out[name + "_rgb"].shape, float(out[name + "_rgb"].mean()))
+    np.savez_compressed(os.path.join(HERE, "pins_hw4_render.npz"), **out)
 
 
 if __name__ == "__main__":

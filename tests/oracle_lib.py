@@ -360,3 +360,45 @@ class RefTxt:
         for i in range(flat.shape[0]):
             self.L.ref_txt_tonemap(flat[i].ctypes.data, out[i].ctypes.data)
         return out.reshape(rgb.shape)
+
+
+def ref_txt_render_fresh(hw, path):
+    """RefTxt(hw, path).render() in a fresh interpreter: hw4 keeps its engine in a file-static variable, so only the
+    first render of a process reproduces the stream of the reference program."""
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.npy")
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); import numpy as np, oracle_lib; "
+                f"np.save({out!r}, oracle_lib.RefTxt({hw}, {path!r}).render())")
+        subprocess.check_call([sys.executable, "-c", code])
+        return np.load(out)
+
+
+class Hw4Oracle:
+    """CPU restatement of hw4 (oracle/oracle_hw4.cpp): sequential single-engine mode = the reference; per-pixel mode = GPU checker."""
+
+    def __init__(self, scene_data):
+        self.data = scene_data
+        L = lib()
+        L.rto_hw4_create.restype = C.c_void_p
+        L.rto_hw4_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.rto_hw4_destroy.argtypes = [C.c_void_p]
+        L.rto_hw4_num_lights.argtypes = [C.c_void_p]
+        L.rto_hw4_render.argtypes = [C.c_void_p] + [C.c_int] * 9 + [C.c_void_p, C.c_void_p, C.c_int]
+        self._h = L.rto_hw4_create(C.byref(scene_data.desc))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rto_hw4_destroy(self._h)
+            self._h = None
+
+    def num_lights(self):
+        return lib().rto_hw4_num_lights(self._h)
+
+    def render(self, width, height, samples, ray_depth, per_pixel_seed, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        lib().rto_hw4_render(self._h, width, height, samples, ray_depth, 1 if per_pixel_seed else 0, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
+        return rgb, rgb8

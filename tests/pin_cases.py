@@ -179,3 +179,7 @@ def loader_case(tmpdir):
 
 # hw2 scenes pinned through the reference's own loader + getPixel (float radiance) and program (PPM md5).
 HW2_CASES = ("hw2_sample_166x128", "hw2_glass_stack")
+
+# hw4 scenes (reference practice scenes at 64x48x8 and a scene with two box lights + an ellipsoid light), pinned in the
+# reference's sequential single-engine order.
+HW4_CASES = ("hw4_practice3_3_64x48x8", "hw4_practice3_5_64x48x8", "hw4_box_and_ellipsoid_lights")

@@ -112,6 +112,20 @@ def test_hw2_whole_tracer_bit_exact(name):
     assert hashlib.md5(_ppm(w, h, rgb8)).hexdigest() == bytes(gold[name + "_md5"]).decode()
 
 
+@pytest.mark.parametrize("name", pin_cases.HW4_CASES)
+def test_hw4_sequential_stream_bit_exact(name):
+    """hw4 (Mix{Cosine, box / ellipsoid lights} over one file-static engine): loader + oracle/oracle_hw4.cpp in sequential
+    mode against the float radiance of the reference's own loader + Scene::getPixel, bit for bit.  Covers the per-object
+    normal_distribution caches and g++'s right-to-left evaluation of the BoxLight sample's constructor arguments."""
+    import importlib
+    rt = importlib.import_module("raytracing-course-hw_amd")
+    gold = np.load(os.path.join(GOLD, "pins_hw4_render.npz"))
+    sd, w, h, spp, depth = rt.load_txt(os.path.join(GOLD, "scenes", "txt", name + ".txt"), rt.RT_INTEGRATOR_HW4)
+    rgb, _ = oracle_lib.Hw4Oracle(sd).render(w, h, spp, depth, per_pixel_seed=False)
+    assert gold[name + "_rgb"].mean() > 0.01
+    assert same(rgb, gold[name + "_rgb"]), f"{name}: linear radiance differs from the reference"
+
+
 def test_gltf_loader_transforms_bit_exact(tmp_path):
     """The product's glTF loader (node TRS chains, `matrix` nodes, inverse-transpose normals, tangents; Figure(v1,v3,v2)
     corner order) against the reference's own transition.h arithmetic (hw8/src/sceneio.cpp:125-134,247-293)."""

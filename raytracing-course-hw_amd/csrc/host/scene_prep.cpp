@@ -396,4 +396,98 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out) {
     }
 }
 
+// ---- hw5 --------------------------------------------------------------------------------------------------------
+namespace {
+struct Q4 { V3 v; float w; };
+inline V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 mulk(float k, V3 p) { return {k * p.x, k * p.y, k * p.z}; }
+inline float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Q4 qmul(Q4 a, Q4 b) { // quaternion.h:36-38
+    return {add(add(mulk(a.w, b.v), mulk(b.w, a.v)), crossr(a.v, b.v)), a.w * b.w - dot3(a.v, b.v)};
+}
+inline V3 qtransform(Q4 q, V3 p) { // quaternion.h:44-46
+    Q4 c{mulk((float)(-1.), q.v), q.w};
+    return qmul(qmul(q, Q4{p, 0.f}), c).v;
+}
+// AABB::AABB(const Figure&), hw5/src/primitives.cpp:171-201
+Box3 figure_box5(const rt_primitive &f) {
+    V3 mn, mx;
+    if (f.type == RT_PRIM_BOX || f.type == RT_PRIM_ELLIPSOID) {
+        mn = mulk((float)(-1.), V3{f.data[0], f.data[1], f.data[2]});
+        mx = V3{f.data[0], f.data[1], f.data[2]};
+    } else {
+        mn = {smin(f.data3[0], smin(f.data[0], f.data2[0])), smin(f.data3[1], smin(f.data[1], f.data2[1])), smin(f.data3[2], smin(f.data[2], f.data2[2]))};
+        mx = {smax(f.data3[0], smax(f.data[0], f.data2[0])), smax(f.data3[1], smax(f.data[1], f.data2[1])), smax(f.data3[2], smax(f.data[2], f.data2[2]))};
+    }
+    Q4 q{V3{f.rotation[0], f.rotation[1], f.rotation[2]}, f.rotation[3]};
+    Q4 r{mulk((float)(-1.), q.v), q.w}; // rotation.conjugate()
+    V3 c0 = qtransform(r, mn);
+    Box3 b;
+    b.lo[0] = b.hi[0] = c0.x; b.lo[1] = b.hi[1] = c0.y; b.lo[2] = b.hi[2] = c0.z;
+    const V3 corners[7] = {{mn.x, mn.y, mx.z}, {mn.x, mx.y, mn.z}, {mn.x, mx.y, mx.z}, {mx.x, mn.y, mn.z}, {mx.x, mn.y, mx.z}, {mx.x, mx.y, mn.z}, {mx.x, mx.y, mx.z}};
+    for (const V3 &c : corners) {
+        V3 p = qtransform(r, c);
+        b.hi[0] = smax(b.hi[0], p.x); b.hi[1] = smax(b.hi[1], p.y); b.hi[2] = smax(b.hi[2], p.z);
+        b.lo[0] = smin(b.lo[0], p.x); b.lo[1] = smin(b.lo[1], p.y); b.lo[2] = smin(b.lo[2], p.z);
+    }
+    for (int k = 0; k < 3; k++) { b.lo[k] = b.lo[k] + f.position[k]; b.hi[k] = b.hi[k] + f.position[k]; }
+    return b;
+}
+} // namespace
+
+void prepare_scene_hw5(const rt_scene_desc &d, PreparedScene5 &out) {
+    const uint32_t n = d.n_primitives;
+    if (n >= 0x7FFFFFFFu) throw std::runtime_error("too many primitives");
+    std::vector<float> keys[3];
+    std::vector<Box3> boxes(n);
+    for (int k = 0; k < 3; k++) keys[k].resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const rt_primitive &f = d.primitives[i];
+        if (f.type < RT_PRIM_ELLIPSOID || f.type > RT_PRIM_TRIANGLE) throw std::runtime_error("bad primitive type");
+        for (int k = 0; k < 3; k++) keys[k][i] = f.position[k];   // bvh.h:61-63 sorts on Figure::position
+        if (f.type != RT_PRIM_PLANE) boxes[i] = figure_box5(f);
+        else memset(&boxes[i], 0, sizeof(Box3));
+    }
+    // Scene::initBVH, hw5/src/scene.cpp:18-23: planes to the back, BVH (which reorders) over the front
+    std::vector<uint32_t> &order = out.figure_order;
+    order.resize(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    out.n_nonplanes = (uint32_t)(std::partition(order.begin(), order.end(), [&](uint32_t i) { return d.primitives[i].type != RT_PRIM_PLANE; }) - order.begin());
+    RefBuilder scene_builder(keys, boxes, order);
+    scene_builder.run(out.n_nonplanes);
+    out.bvh_depth = scene_builder.depth;
+    // FiguresMix::FiguresMix on a copy of the reordered list, hw5/src/include/distributions.h:180-198
+    std::vector<uint32_t> lorder = order;
+    uint32_t n_lights = (uint32_t)(std::partition(lorder.begin(), lorder.end(), [&](uint32_t i) {
+        const rt_primitive &f = d.primitives[i];
+        if (f.emission[0] == 0 && f.emission[1] == 0 && f.emission[2] == 0) return false;
+        return f.type == RT_PRIM_BOX || f.type == RT_PRIM_ELLIPSOID || f.type == RT_PRIM_TRIANGLE;
+    }) - lorder.begin());
+    RefBuilder light_builder(keys, boxes, lorder);
+    light_builder.run(n_lights);
+    out.light_bvh_depth = light_builder.depth;
+    out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
+    std::vector<uint32_t> scene_leaf_last, light_leaf_last;
+    encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
+    encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    auto make = [&](uint32_t src) {
+        const rt_primitive &f = d.primitives[src];
+        GpuFig5 g;
+        memset(&g, 0, sizeof g);
+        for (int k = 0; k < 3; k++) {
+            g.data[k] = f.data[k]; g.data2[k] = f.data2[k]; g.data3[k] = f.data3[k]; g.position[k] = f.position[k];
+            g.color[k] = f.color[k]; g.emission[k] = f.emission[k];
+        }
+        for (int k = 0; k < 4; k++) g.rotation[k] = f.rotation[k];
+        g.type = f.type; g.kind = f.kind; g.ior = f.ior;
+        return g;
+    };
+    out.figs.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.figs[i] = make(order[i]);
+    for (uint32_t i : scene_leaf_last) out.figs[i].last = 1;
+    out.lights.resize(n_lights);
+    for (uint32_t i = 0; i < n_lights; i++) out.lights[i] = make(lorder[i]);
+    for (uint32_t i : light_leaf_last) out.lights[i].last = 1;
+}
+
 } // namespace rtamd

@@ -2,6 +2,7 @@
 #include "../../../include/rtamd.h"
 #include "../device/rt_types.h"
 #include "../device/rt_types_hw6.h"
+#include "../device/rt_types_hw5.h"
 #include <cstdint>
 #include <vector>
 
@@ -34,5 +35,15 @@ struct PreparedScene6 {
     uint32_t bvh_depth = 0, light_bvh_depth = 0, ref_bvh_depth = 0;
 };
 void prepare_scene_hw6(const rt_scene_desc &desc, PreparedScene6 &out);
+
+// hw5 flavour (.txt scene with TRIANGLE figures): the reference's figure order, BVH and light list / light BVH
+// (hw5/src/scene.cpp:8-23, hw5/src/include/distributions.h:180-198), both trees in the reference's topology.
+struct PreparedScene5 {
+    std::vector<GpuNode> nodes, light_nodes;
+    std::vector<GpuFig5> figs, lights;
+    std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index
+    uint32_t n_nonplanes = 0, bvh_depth = 0, light_bvh_depth = 0;
+};
+void prepare_scene_hw5(const rt_scene_desc &desc, PreparedScene5 &out);
 
 } // namespace rtamd

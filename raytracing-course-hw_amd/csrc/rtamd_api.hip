@@ -20,6 +20,7 @@
 #include "device/rt_kernels_txt.h"
 #include "device/rt_kernels_hw2.h"
 #include "device/rt_kernels_hw4.h"
+#include "device/rt_kernels_hw5.h"
 #include <cstdlib>
 
 namespace rtamd {
@@ -70,6 +71,8 @@ struct rt_scene {
     SceneView view{};
     SceneView6 view6{};
     SceneViewTxt viewt{};
+    SceneView5 view5{};
+    bool txt_has_triangles = false; // TRIANGLE figures exist only in the hw5 grammar: such a scene renders with RT_INTEGRATOR_HW5 only
     int flavor = RT_INTEGRATOR_HW8; // which integrator this scene was prepared for
     std::vector<void *> allocations;
     rt_scene_info info{};
@@ -124,7 +127,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                 const rt_primitive &p = desc->primitives[i];
                 GpuPrim &g = prims[i];
                 memset(&g, 0, sizeof g);
-                if (p.type < RT_PRIM_ELLIPSOID || p.type > RT_PRIM_BOX) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: bad primitive type");
+                if (p.type < RT_PRIM_ELLIPSOID || p.type > RT_PRIM_TRIANGLE) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: bad primitive type");
+                if (p.type == RT_PRIM_TRIANGLE) s->txt_has_triangles = true;
                 for (int k = 0; k < 3; k++) { g.data[k] = p.data[k]; g.position[k] = p.position[k]; g.color[k] = p.color[k]; g.emission[k] = p.emission[k]; }
                 for (int k = 0; k < 4; k++) g.rotation[k] = p.rotation[k];
                 g.type = p.type; g.kind = p.kind; g.ior = p.ior;
@@ -160,6 +164,23 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             }
             V.n_light_prims = (uint32_t)light_prims.size();
             if (!light_prims.empty()) { V.light_prims = upload(light_prims, bytes); s->allocations.push_back((void *)V.light_prims); }
+            { // hw5 structures: reference figure order, BVH over the non-planes, light list + light BVH
+                PreparedScene5 P5;
+                prepare_scene_hw5(*desc, P5);
+                SceneView5 &V5 = s->view5;
+                V5.nodes = upload(P5.nodes, bytes); s->allocations.push_back((void *)V5.nodes);
+                V5.figs = upload(P5.figs, bytes); s->allocations.push_back((void *)V5.figs);
+                V5.light_nodes = upload(P5.light_nodes, bytes); s->allocations.push_back((void *)V5.light_nodes);
+                if (!P5.lights.empty()) { V5.lights = upload(P5.lights, bytes); s->allocations.push_back((void *)V5.lights); }
+                V5.n_figs = (uint32_t)P5.figs.size(); V5.n_nonplanes = P5.n_nonplanes; V5.n_lights = (uint32_t)P5.lights.size();
+                for (int k = 0; k < 3; k++) {
+                    V5.cam_pos[k] = V.cam_pos[k]; V5.cam_right[k] = V.cam_right[k]; V5.cam_up[k] = V.cam_up[k]; V5.cam_fwd[k] = V.cam_fwd[k]; V5.bg[k] = V.bg[k];
+                }
+                V5.tan_fov_x = V.tan_fov_x;
+                s->light_order = P5.light_order;
+                s->info.n_lights = V5.n_lights; s->info.n_bvh_nodes = (uint32_t)P5.nodes.size(); s->info.n_light_bvh_nodes = (uint32_t)P5.light_nodes.size();
+                s->info.bvh_depth = P5.bvh_depth; s->info.light_bvh_depth = P5.light_bvh_depth;
+            }
             s->flavor = RT_INTEGRATOR_HW3;
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
@@ -374,7 +395,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
     if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6 && p->integrator != RT_INTEGRATOR_HW3 && p->integrator != RT_INTEGRATOR_HW1 &&
-        p->integrator != RT_INTEGRATOR_HW2 && p->integrator != RT_INTEGRATOR_HW4)
+        p->integrator != RT_INTEGRATOR_HW2 && p->integrator != RT_INTEGRATOR_HW4 && p->integrator != RT_INTEGRATOR_HW5)
         return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown integrator");
     const bool txt_scene = scene->flavor == RT_INTEGRATOR_HW3;
     const bool txt_integrator = p->integrator >= RT_INTEGRATOR_HW1 && p->integrator <= RT_INTEGRATOR_HW5;
@@ -420,6 +441,9 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (scene->info.bvh_depth > WF_STACK || scene->info.light_bvh_depth > WF_STACK || scene->info.n_triangles >= 0x40000000u) use_wavefront = false;
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
+        if (txt_scene && scene->txt_has_triangles && p->integrator != RT_INTEGRATOR_HW5) return fail(RT_ERR_INVALID_ARG, "rt_render: a .txt scene with TRIANGLE figures renders with RT_INTEGRATOR_HW5 only");
+        if (p->integrator == RT_INTEGRATOR_HW5 && R.ray_depth > RT4_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw5 ray_depth above 8");
+        if (p->integrator == RT_INTEGRATOR_HW5 && (scene->info.bvh_depth > RT5_STACK || scene->info.light_bvh_depth > RT5_STACK)) return fail(RT_ERR_LIMIT, "rt_render: hw5 BVH deeper than 64");
         if (p->integrator == RT_INTEGRATOR_HW4 && R.ray_depth > RT4_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw4 ray_depth above 8");
         if (p->integrator == RT_INTEGRATOR_HW4 && scene->viewt.n_light_prims > RT4_MAX_LIGHTS) return fail(RT_ERR_LIMIT, "rt_render: hw4 supports at most 32 emissive box/ellipsoid lights");
         if (p->integrator == RT_INTEGRATOR_HW2 && R.ray_depth > RT2_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw2 ray_depth above 16");
@@ -436,6 +460,10 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             } else if (p->integrator == RT_INTEGRATOR_HW1) {
                 uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
                 hipLaunchKernelGGL(dev::render_hw1_kernel, dim3((npx + 255) / 256), dim3(256), 0, stream, scene->viewt, R.width, R.height, txt_tan_fov_y, d_rgb, d_rgb8);
+                HIP_CHECK(hipGetLastError());
+                launches = 1;
+            } else if (p->integrator == RT_INTEGRATOR_HW5) {
+                hipLaunchKernelGGL(dev::render_hw5_kernel, dim3(blocks), dim3(64), 0, stream, scene->view5, R, txt_tan_fov_y, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
             } else if (p->integrator == RT_INTEGRATOR_HW4) {

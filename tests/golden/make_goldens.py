@@ -96,6 +96,17 @@ def main():
         out[name + "_rgb"] = oracle_lib.ref_txt_render_fresh(4, os.path.join(txt, name + ".txt"))
         print(name, out[name + "_rgb"].shape, float(out[name + "_rgb"].mean()))
     np.savez_compressed(os.path.join(HERE, "pins_hw4_render.npz"), **out)
+    # hw5: float radiance through the reference's own loader + Scene::getPixel(rng(y*W+x)), and the program's PPM md5
+    out = {}
+    for name in pin_cases.HW5_CASES:
+        path = os.path.join(txt, name + ".txt")
+        out[name + "_rgb"] = oracle_lib.RefTxt(5, path).render()
+        with tempfile.TemporaryDirectory() as td:
+            ppm = os.path.join(td, "o.ppm")
+            subprocess.run([oracle_lib.ref_path("hw5_main"), path, ppm], check=True, stderr=subprocess.DEVNULL)
+            out[name + "_md5"] = np.frombuffer(hashlib.md5(open(ppm, "rb").read()).hexdigest().encode(), np.uint8)
+        print(name, out[name + "_rgb"].shape, float(out[name + "_rgb"].mean()), bytes(out[name + "_md5"]).decode())
+    np.savez_compressed(os.path.join(HERE, "pins_hw5_render.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -402,3 +402,37 @@ class Hw4Oracle:
         rgb8 = np.zeros((h, w, 3), np.uint8)
         lib().rto_hw4_render(self._h, width, height, samples, ray_depth, 1 if per_pixel_seed else 0, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
         return rgb, rgb8
+
+
+class Hw5Oracle:
+    """CPU restatement of hw5 (oracle/oracle_hw5.cpp): per-pixel engines, as the reference program itself."""
+
+    def __init__(self, scene_data):
+        self.data = scene_data
+        L = lib()
+        L.rto_hw5_create.restype = C.c_void_p
+        L.rto_hw5_create.argtypes = [C.POINTER(rt.rt_scene_desc)]
+        L.rto_hw5_destroy.argtypes = [C.c_void_p]
+        L.rto_hw5_num_lights.argtypes = [C.c_void_p]
+        L.rto_hw5_num_lights.restype = C.c_uint32
+        L.rto_hw5_orders.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rto_hw5_render.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int]
+        self._h = L.rto_hw5_create(C.byref(scene_data.desc))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rto_hw5_destroy(self._h)
+            self._h = None
+
+    def orders(self):
+        fo = np.zeros(len(self.data.primitives), np.uint32)
+        lo = np.zeros(max(1, lib().rto_hw5_num_lights(self._h)), np.uint32)
+        lib().rto_hw5_orders(self._h, fo.ctypes.data, lo.ctypes.data)
+        return fo, lo[:lib().rto_hw5_num_lights(self._h)]
+
+    def render(self, width, height, samples, ray_depth, rect=None, threads=0):
+        x0, y0, w, h = rect if rect else (0, 0, width, height)
+        rgb = np.zeros((h, w, 3), np.float32)
+        rgb8 = np.zeros((h, w, 3), np.uint8)
+        lib().rto_hw5_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads)
+        return rgb, rgb8

@@ -183,3 +183,7 @@ HW2_CASES = ("hw2_sample_166x128", "hw2_glass_stack")
 # hw4 scenes (reference practice scenes at 64x48x8 and a scene with two box lights + an ellipsoid light), pinned in the
 # reference's sequential single-engine order.
 HW4_CASES = ("hw4_practice3_3_64x48x8", "hw4_practice3_5_64x48x8", "hw4_box_and_ellipsoid_lights")
+
+# hw5 scenes: a reference practice scene through the hw5 grammar, and tools/gen_hw5_fixture.py's mixed-figure scene
+# (48+2 TRIANGLE figures with own position/rotation, box / ellipsoid / triangle lights, three planes).
+HW5_CASES = ("hw5_practice3_5_64x48x8", "hw5_mixed_figures")

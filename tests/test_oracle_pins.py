@@ -126,6 +126,22 @@ def test_hw4_sequential_stream_bit_exact(name):
     assert same(rgb, gold[name + "_rgb"]), f"{name}: linear radiance differs from the reference"
 
 
+@pytest.mark.parametrize("name", pin_cases.HW5_CASES)
+def test_hw5_whole_integrator_bit_exact(name):
+    """hw5 (TRIANGLE figures, BVH sorted on Figure::position, box / ellipsoid / triangle lights, long-double eps, engine
+    per pixel): loader + oracle/oracle_hw5.cpp against the float radiance of the reference's own loader + getPixel, bit
+    for bit, and against the md5 of the PPM the unmodified hw5 program wrote."""
+    import hashlib
+    import importlib
+    rt = importlib.import_module("raytracing-course-hw_amd")
+    gold = np.load(os.path.join(GOLD, "pins_hw5_render.npz"))
+    sd, w, h, spp, depth = rt.load_txt(os.path.join(GOLD, "scenes", "txt", name + ".txt"), rt.RT_INTEGRATOR_HW5)
+    rgb, rgb8 = oracle_lib.Hw5Oracle(sd).render(w, h, spp, depth)
+    assert gold[name + "_rgb"].mean() > 0.01
+    assert same(rgb, gold[name + "_rgb"]), f"{name}: linear radiance differs from the reference"
+    assert hashlib.md5(_ppm(w, h, rgb8)).hexdigest() == bytes(gold[name + "_md5"]).decode()
+
+
 def test_gltf_loader_transforms_bit_exact(tmp_path):
     """The product's glTF loader (node TRS chains, `matrix` nodes, inverse-transpose normals, tangents; Figure(v1,v3,v2)
     corner order) against the reference's own transition.h arithmetic (hw8/src/sceneio.cpp:125-134,247-293)."""

@@ -1,7 +1,8 @@
 // CLI with the reference's surfaces:
 //   hw6-hw8 (hw8/src/main.cpp:7-18, hw8/run.sh):  rtamd_main <scene.gltf> <width> <height> <samples> <out.ppm> [<envmap.png>]
 //   hw1-hw5 (hw1/src/main.cpp:7-14, hw1/run.sh):  rtamd_main <scene.txt> <out.ppm>
-// Which snapshot's integrator replays the scene: RTAMD_SNAPSHOT=hw8 (default for glTF) | hw6 | hw3 (default for .txt) | hw1.
+// Which snapshot's integrator replays the scene: RTAMD_SNAPSHOT=hw8 (default for glTF) | hw6, and for .txt scenes
+// hw1 | hw2 | hw3 (default) | hw4 | hw5 (grammar and integrator of that snapshot).
 // The host only parses, prepares and writes the PPM; the render loop runs on the GPU through the C-ABI.
 #include "../../../include/rtamd.h"
 #include <cstdio>
@@ -23,9 +24,10 @@ int main(int argc, const char *argv[]) {
     p.struct_size = sizeof p;
     const char *out_path = nullptr;
     if (argc == 3) { // .txt scene: everything comes from the file
-        int flavor = (snap && strcmp(snap, "hw1") == 0) ? RT_INTEGRATOR_HW1 : RT_INTEGRATOR_HW3;
+        int flavor = RT_INTEGRATOR_HW3;
+        if (snap && strlen(snap) == 3 && snap[0] == 'h' && snap[1] == 'w' && snap[2] >= '1' && snap[2] <= '5') flavor = snap[2] - '0';
         if (rt_load_txt(argv[1], flavor, &hs, &p.width, &p.height, &p.samples, &p.ray_depth) != RT_OK) return die();
-        if (flavor == RT_INTEGRATOR_HW1) p.samples = 1;
+        if (flavor == RT_INTEGRATOR_HW1 || flavor == RT_INTEGRATOR_HW2) p.samples = 1;
         p.integrator = flavor;
         out_path = argv[2];
     } else if (argc >= 6) {

@@ -29,6 +29,19 @@ def test_cli_txt_surface_hw1_md5(tmp_path):
     assert hashlib.md5(out.read_bytes()).hexdigest() == "353a1038e8aaa368d2957931be2cf87d"  # reference program's file
 
 
+@pytest.mark.parametrize("snap,scene,gold_file", [("hw2", "hw2_sample", "pins_hw2_render.npz"), ("hw2", "hw2_glass_stack", "pins_hw2_render.npz"),
+                                                   ("hw5", "hw5_mixed_figures", "pins_hw5_render.npz"), ("hw5", "hw5_practice3_5_64x48x8", "pins_hw5_render.npz")])
+def test_cli_txt_surface_matches_the_reference_programs_file(tmp_path, snap, scene, gold_file):
+    """hw2 (deterministic) and hw5 (engine per pixel) are the .txt snapshots whose program output is reproducible in
+    parallel: `rtamd_main scene.txt out.ppm` must write the very file the unmodified reference program wrote."""
+    out = tmp_path / "o.ppm"
+    env = dict(os.environ, RTAMD_SNAPSHOT=snap)
+    r = subprocess.run([MAIN, os.path.join(SCENES, "txt", scene + ".txt"), str(out)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "FINISH" in r.stderr, r.stderr
+    gold = np.load(os.path.join(ROOT, "tests", "golden", gold_file))
+    assert hashlib.md5(out.read_bytes()).hexdigest() == bytes(gold[scene + "_md5"]).decode()
+
+
 def test_cli_reports_errors(tmp_path):
     r = subprocess.run([MAIN, str(tmp_path / "missing.gltf"), "8", "8", "1", str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "error" in r.stderr

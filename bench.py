@@ -176,6 +176,18 @@ def main():
                     "s_bar": round(s_bar, 3), "p_bar": round(p_bar, 3),
                     "node_visits_per_sample": round(cst.node_visits / max(1, cst.samples), 2),
                     "triangle_tests_per_sample": round(cst.triangle_tests / max(1, cst.samples), 2)}
+        # HBM-side traffic of the dominant kernel comes from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need separate
+        # passes and cannot be read from inside this process): tools/pmc_traffic.py condenses such a run of THIS command
+        # into profiles/traffic_latest.json, which is reported here with its provenance when the workload matches.
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if wavefront and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and world == 1 and tj.get("kernel") == roofline["kernel"]:
+                    roofline["traffic"] = tj["bytes_per_launch"]
+                    roofline["traffic_source"] = tj.get("source", "profiles/traffic_latest.json")
+            except (OSError, ValueError, KeyError):
+                pass
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE — they do not fit in one pass on gfx950) of
+`bench.py --steps 1 --spp 4 --no-cpu-baseline` into profiles/traffic_latest.json: memory-side bytes per launch of the
+dominant kernel, for bench.py's roofline.traffic.
+
+usage: pmc_traffic.py <dir with the counter_collection CSVs> <workload name> <out.json>
+
+FETCH_SIZE / WRITE_SIZE are reported in KB and count the L2's fabric-side requests, Infinity-Cache hits included
+(MI355X_MICROARCH.md, HBM section).  The guide's gfx950 correction — FETCH_SIZE tallies 128-byte requests at 64 B, so
+double it — is calibrated for wide coalesced reads; this kernel's 16-byte-per-lane loads are divergent (one line per
+lane), which the guide calls uncalibrated, so both the raw and the doubled figure are kept and `bytes_per_launch` uses
+the doubled one (the upper bound)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    root, workload, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    kernel = "wf_trace_kernel"
+    tot = {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]}
+    for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel + "<false>" in r["Kernel_Name"] and r["Counter_Name"] in tot:
+                tot[r["Counter_Name"]][0] += 1
+                tot[r["Counter_Name"]][1] += float(r["Counter_Value"])
+    if not tot["FETCH_SIZE"][0] or not tot["WRITE_SIZE"][0]:
+        raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for " + kernel)
+    fetch_kb = tot["FETCH_SIZE"][1] / tot["FETCH_SIZE"][0]
+    write_kb = tot["WRITE_SIZE"][1] / tot["WRITE_SIZE"][0]
+    j = {"workload": workload, "kernel": kernel, "launches_sampled": tot["FETCH_SIZE"][0],
+         "fetch_size_kb_per_launch_raw": round(fetch_kb, 1), "write_size_kb_per_launch": round(write_kb, 1),
+         "bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
+         "bytes_per_launch_uncorrected": int((fetch_kb + write_kb) * 1024),
+         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --spp 4 --no-cpu-baseline`; "
+                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); fabric-side requests, Infinity-Cache hits included"}
+    json.dump(j, open(out, "w"), indent=1)
+    print(json.dumps(j))
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,31 @@ def test_full_config_1920x1080x256_crops_match_oracle(rt, tmp_path):
     scene.close()
 
 
+def test_config4_3840x2160x1024_one_of_eight_shards_matches_oracle(rt, tmp_path):
+    """BASELINE.json configs[4] (3840x2160x1024 spp on 8 GPUs): exactly the work ONE of the eight ranks does — shard 0 of 8
+    of the 4K frame, 1,012 tiles of 32x32, 1024 samples per pixel — rendered on this one GPU; the oracle replays three of
+    that shard's tiles (32x32x1024 = 1 M camera samples each)."""
+    import gen_synth_room
+    path, _ = gen_synth_room.generate(str(tmp_path), 64, 50, 43)
+    sd = rt.load_gltf(path)
+    scene = rt.Scene(sd)
+    W, H, SPP, N = 3840, 2160, 1024, 8
+    buf, _, st = scene.render(W, H, SPP, shard_index=0, shard_count=N, want_rgb8=False)
+    tiles_x = W // 32
+    n_mine = len(range(0, tiles_x * ((H + 31) // 32), N))
+    print(f"config 4, shard 0/8: {n_mine} tiles, {st.kernel_ms / 1e3:.2f} s kernel = {st.samples / st.kernel_ms / 1e3:.1f} Msamples/s on this GPU")
+    tiles = buf.reshape(n_mine, 32, 32, 3)
+    orc = oracle_lib.Hw8Oracle(sd)
+    for k in (5, n_mine // 2 + 3, n_mine - 40):          # (the last tile row is cut by the frame edge: rows beyond H are zero padding)
+        t = k * N                                   # global tile index of this shard's k-th tile
+        x0, y0 = (t % tiles_x) * 32, (t // tiles_x) * 32
+        ref, _, _ = orc.render(W, H, SPP, rect=(x0, y0, 32, 32))
+        rmse = float(np.sqrt(np.mean((tiles[k].astype(np.float64) - ref) ** 2)))
+        print(f"  tile {t} at ({x0},{y0}): rmse {rmse:.3e} bit_exact {np.array_equal(tiles[k], ref)}")
+        assert y0 + 32 <= H and ref.mean() > 0.01 and rmse < RMSE_TOL
+    scene.close()
+
+
 @pytest.mark.parametrize("name", ["sphere", "sphere_metallic", "sphere_roughness"])
 def test_reference_sphere_scenes_with_environment_map(rt, tmp_path, name):
     """The reference's three emitter-less hw8 example scenes (normal map on a dielectric / on a metal, metallic-roughness

@@ -121,7 +121,7 @@ struct Node {
     std::vector<size_t> children;
     Mat4 total;
 };
-struct BufferView { size_t buffer, byteLength, byteOffset; };
+struct BufferView { size_t buffer, byteLength, byteOffset, byteStride; };
 struct Accessor { size_t bufferView, count, componentType; std::string type; size_t byteOffset; };
 struct Prim { size_t position; std::optional<size_t> texcoord, normal, tangent; size_t indices, material; };
 
@@ -153,10 +153,26 @@ struct Loader {
         return buffers[v.buffer].data() + off;
     }
     std::vector<float> load_floats(size_t index, int comps) { // loadVec2s/3s/4s, sceneio.cpp:136-191
+        // Extension: an interleaved bufferView (byteStride larger than the element) is gathered; the reference reads every
+        // accessor as tightly packed (sceneio.cpp:136-191) and would produce garbage vertices for such a file.
+        const size_t elem = 4 * (size_t)comps;
+        size_t stride = elem;
+        if (index < accessors.size() && accessors[index].bufferView < views.size() && views[accessors[index].bufferView].byteStride > elem)
+            stride = views[accessors[index].bufferView].byteStride;
         size_t count;
-        const uint8_t *p = accessor_ptr(index, 4 * comps, count, true);
+        if (stride == elem) {
+            const uint8_t *p = accessor_ptr(index, elem, count, true);
+            std::vector<float> out(count * comps);
+            memcpy(out.data(), p, out.size() * 4);
+            return out;
+        }
+        const uint8_t *p = accessor_ptr(index, 0, count, true);
+        const Accessor &a = accessors[index];
+        const BufferView &v = views[a.bufferView];
+        size_t off = v.byteOffset + a.byteOffset;
+        if (count && off + (count - 1) * stride + elem > buffers[v.buffer].size()) throw std::runtime_error("glTF: strided accessor overruns its buffer");
         std::vector<float> out(count * comps);
-        memcpy(out.data(), p, out.size() * 4);
+        for (size_t i = 0; i < count; i++) memcpy(out.data() + i * comps, p + i * stride, elem);
         return out;
     }
 
@@ -185,7 +201,8 @@ struct Loader {
         // loadBufferViews, sceneio.cpp:28-37 (byteOffset defaulted to 0 instead of required)
         if (const Json *vs = doc.find("bufferViews"))
             for (const Json &v : vs->arr)
-                views.push_back(BufferView{v.at("buffer").as_uint(), v.at("byteLength").as_uint(), v.has("byteOffset") ? v.at("byteOffset").as_uint() : 0u});
+                views.push_back(BufferView{v.at("buffer").as_uint(), v.at("byteLength").as_uint(), v.has("byteOffset") ? v.at("byteOffset").as_uint() : 0u,
+                                           v.has("byteStride") ? v.at("byteStride").as_uint() : 0u});
         load_nodes();
         // restoreNodeParents + calculateTransitions, sceneio.cpp:117-134
         for (size_t i = 0; i < nodes.size(); i++)
@@ -323,8 +340,9 @@ struct Loader {
                 }
                 size_t n_idx;
                 const Accessor &ia = accessors.at(pr.indices);
-                size_t isz = ia.componentType == 5123 ? 2 : 4;
-                if (ia.componentType != 5123 && ia.componentType != 5125) throw std::runtime_error("glTF: index componentType must be 5123 or 5125");
+                // 5123 (u16) and 5125 (u32) as the reference; 5121 (u8) is an extension (the reference would misread it as u32)
+                size_t isz = ia.componentType == 5123 ? 2 : (ia.componentType == 5121 ? 1 : 4);
+                if (ia.componentType != 5121 && ia.componentType != 5123 && ia.componentType != 5125) throw std::runtime_error("glTF: index componentType must be 5121, 5123 or 5125");
                 const uint8_t *ip = accessor_ptr(pr.indices, isz, n_idx, false); // accessor byteOffset ignored like :258-269
                 const Mat4 &M = node.total;
                 Mat4 NM = M.inverted().transposed();
@@ -332,7 +350,8 @@ struct Loader {
                 for (size_t i = 0; i + 2 < n_idx; i += 3) {
                     size_t id[3];
                     for (int k = 0; k < 3; k++) {
-                        if (isz == 2) { uint16_t v; memcpy(&v, ip + 2 * (i + k), 2); id[k] = v; }
+                        if (isz == 1) id[k] = ip[i + k];
+                        else if (isz == 2) { uint16_t v; memcpy(&v, ip + 2 * (i + k), 2); id[k] = v; }
                         else { uint32_t v; memcpy(&v, ip + 4 * (i + k), 4); id[k] = v; }
                         if (id[k] >= nv || (full && (id[k] >= uv.size() / 2 || id[k] >= nrm.size() / 3 || id[k] >= tan.size() / 4)))
                             throw std::runtime_error("glTF: vertex index out of range");

@@ -88,3 +88,38 @@ def test_no_gpu_means_loud_failure_not_fallback(rt, sphere_scene):
     with pytest.raises(rt.RtError) as e:
         rt.Scene(sphere_scene)
     assert e.value.code == rt.RT_ERR_NO_DEVICE
+
+
+def test_gltf_interleaved_vertex_buffer_and_u8_indices_load_like_the_tight_layout(rt, tmp_path):
+    """Extension beyond the reference: one interleaved bufferView with byteStride (pos|nrm|uv|tan = 48 B per
+    vertex) and 8-bit indices must load to exactly the arrays of the same mesh stored as four tight views with 16-bit
+    indices — the layout the reference understands, whose arithmetic is pinned in test_oracle_pins."""
+    import json
+    import pin_cases
+    tight_path, lc = pin_cases.loader_case(str(tmp_path / "tight"))
+    g = json.load(open(tight_path))
+    tight_blob = open(os.path.join(str(tmp_path / "tight"), "loader_case.bin"), "rb").read()
+    n = 24
+    pos = np.frombuffer(tight_blob, np.float32, n * 3, 0).reshape(n, 3)
+    nrm = np.frombuffer(tight_blob, np.float32, n * 3, pos.nbytes).reshape(n, 3)
+    uv = np.frombuffer(tight_blob, np.float32, n * 2, pos.nbytes + nrm.nbytes).reshape(n, 2)
+    tan = np.frombuffer(tight_blob, np.float32, n * 4, pos.nbytes + nrm.nbytes + uv.nbytes).reshape(n, 4)
+    inter = np.concatenate([pos, nrm, uv, tan], axis=1).astype(np.float32)          # 12 floats = 48 B per vertex
+    idx8 = np.arange(n, dtype=np.uint8)
+    blob = inter.tobytes() + idx8.tobytes()
+    g["bufferViews"] = [{"buffer": 0, "byteOffset": 0, "byteLength": inter.nbytes, "byteStride": 48},
+                        {"buffer": 0, "byteOffset": inter.nbytes, "byteLength": n}]
+    g["accessors"] = [{"bufferView": 0, "byteOffset": 0, "componentType": 5126, "count": n, "type": "VEC3"},
+                      {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": n, "type": "VEC3"},
+                      {"bufferView": 0, "byteOffset": 24, "componentType": 5126, "count": n, "type": "VEC2"},
+                      {"bufferView": 0, "byteOffset": 32, "componentType": 5126, "count": n, "type": "VEC4"},
+                      {"bufferView": 1, "componentType": 5121, "count": n, "type": "SCALAR"}]
+    g["buffers"] = [{"byteLength": len(blob), "uri": "inter.bin"}]
+    d = tmp_path / "inter"
+    d.mkdir()
+    (d / "inter.bin").write_bytes(blob)
+    json.dump(g, open(d / "inter.gltf", "w"))
+    a, b = rt.load_gltf(tight_path), rt.load_gltf(str(d / "inter.gltf"))
+    assert a.positions.shape == b.positions.shape == (16, 9)
+    for name in ("positions", "normals", "texcoords", "tangents"):
+        assert np.array_equal(getattr(a, name).view(np.uint32), getattr(b, name).view(np.uint32)), name

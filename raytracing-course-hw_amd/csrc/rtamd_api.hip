@@ -370,6 +370,8 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     uint32_t blocks_per_cu = 4u;                                      // measured best (5 fit: 5 x 32 KB LDS per CU)
     if (const char *e = getenv("RTAMD_WF_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : blocks_per_cu;
     const uint32_t persistent_blocks = (uint32_t)scene->n_cus * blocks_per_cu;
+    int dyn256 = 64;                                                   // share of each queue (of 256) handed out dynamically at the tail
+    if (const char *e = getenv("RTAMD_WF_DYNAMIC_256")) dyn256 = atoi(e) < 0 ? 0 : (atoi(e) > 255 ? 255 : atoi(e));
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
     const int t_refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL), t_batch = env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH);
     const int l_refill = env_int("RTAMD_LIGHT_REFILL", WF_REFILL), l_batch = env_int("RTAMD_LIGHT_LEAF_BATCH", WF_LEAF_BATCH);
@@ -380,12 +382,12 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     if (time_trace) while (scene->ev_pool.size() < 2 * rounds) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r], stream));
-        if (count) hipLaunchKernelGGL(dev::wf_trace_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch);
-        else hipLaunchKernelGGL(dev::wf_trace_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch);
+        if (count) hipLaunchKernelGGL(dev::wf_trace_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, dyn256);
+        else hipLaunchKernelGGL(dev::wf_trace_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, dyn256);
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r + 1], stream));
         hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
-        if (count) hipLaunchKernelGGL(dev::wf_light_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch);
-        else hipLaunchKernelGGL(dev::wf_light_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch);
+        if (count) hipLaunchKernelGGL(dev::wf_light_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch, dyn256);
+        else hipLaunchKernelGGL(dev::wf_light_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch, dyn256);
         hipLaunchKernelGGL(dev::wf_update_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
     }
     HIP_CHECK(hipGetLastError());

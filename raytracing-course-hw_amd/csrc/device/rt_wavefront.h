@@ -176,12 +176,14 @@ __global__ __launch_bounds__(256) void wf_init_kernel(SceneView S, RenderView R,
 #define WF_REFILL 16
 #define WF_LEAF_BATCH 20
 #define WF_STEAL_CHUNK 64u
-struct WfSlice { uint32_t pos, end, dyn_base, dyn_end; uint32_t *head; bool done; };
+struct WfSlice { uint32_t pos, end, dyn_base, dyn_end, chunk; uint32_t *head; bool done; };
 // The first (256 - dyn256)/256 of the queue is cut into one static slice per wave; the rest is handed out in
 // WF_STEAL_CHUNK pieces through one atomic counter to waves whose slice has run dry, which evens out the tail
 // (the slowest of ~4k static slices is ~20 % above the mean).
 RT_DEV WfSlice wf_slice(uint32_t count, uint32_t *head, int dyn256) {
     uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t chunk = (uint32_t)dyn256 >> 8;           // packed by the host: chunk << 8 | share
+    dyn256 &= 255;
     uint32_t stat = (uint32_t)(((unsigned long long)count * (unsigned)(256 - dyn256)) >> 8);
     uint32_t per = (stat + nwaves - 1) / nwaves;
     per = (per + 63u) & ~63u;
@@ -190,19 +192,19 @@ RT_DEV WfSlice wf_slice(uint32_t count, uint32_t *head, int dyn256) {
     WfSlice s;
     s.pos = wid * per < stat ? wid * per : stat;
     s.end = s.pos + per < stat ? s.pos + per : stat;
-    s.dyn_base = stat; s.dyn_end = count; s.head = head;
+    s.dyn_base = stat; s.dyn_end = count; s.head = head; s.chunk = chunk ? chunk : WF_STEAL_CHUNK;
     s.done = stat >= count;
     return s;
 }
 // Wave-uniform: fetch the next dynamic chunk when the slice is empty.
 RT_DEV void wf_steal(WfSlice &s) {
     uint32_t off = 0;
-    if ((threadIdx.x & 63) == 0) off = atomicAdd(s.head, WF_STEAL_CHUNK);
+    if ((threadIdx.x & 63) == 0) off = atomicAdd(s.head, s.chunk);
     off = __shfl(off, 0);
     uint32_t b = s.dyn_base + off;
     if (b >= s.dyn_end) { s.done = true; return; }
     s.pos = b;
-    s.end = b + WF_STEAL_CHUNK < s.dyn_end ? b + WF_STEAL_CHUNK : s.dyn_end;
+    s.end = b + s.chunk < s.dyn_end ? b + s.chunk : s.dyn_end;
 }
 // Hands queue positions to the lanes that want one; returns true for lanes that got `item`.
 RT_DEV bool wf_take(WfSlice &s, bool want, uint32_t &item) {

@@ -3,18 +3,24 @@
 // The reference's per-pixel loop (hw8/src/scene.cpp:84-177) is a chain of dependent stages per pixel
 // (closest hit -> shade/sample -> light-pdf traversal -> throughput update -> next bounce or next
 // sample).  A pixel's samples must stay sequential (they share one minstd_rand stream), but pixels
-// are independent, so every pixel carries its path state in HBM and each stage runs as its own kernel
-// over a queue of the pixels that are at that stage:
+// are independent, so every pixel carries its path state in HBM and the stages run as kernels over
+// queues of the pixels that are at that stage.  Two launches per round:
 //
-//   round r:  trace(r)   closest-hit BVH traversal, persistent waves, lanes refill from the queue
-//             shade(r)   attribute/texture fetch, Mix::sample, BRDF; ends paths that miss / early-out
-//             light(r)   all-hits light-BVH sum (FiguresMix::getTotalPdf), persistent + refill
-//             update(r)  Mix::pdf, throughput, clamp; pushes the next bounce or ends the path
+//   traverse(r)  one persistent launch, two wave populations sharing the CUs:
+//                  * closest hit for every ray of q_trace(r)           (bvh.h:111-142)
+//                  * all-hits light sum for every ray of q_light(r)    (FiguresMix::getTotalPdf)
+//                The sampled direction of a bounce is both its light-pdf query and the next bounce's ray, and
+//                tracing draws no random numbers, so the next closest hit is traced SPECULATIVELY next to the pdf
+//                sum of the bounce that produced it; the clamp test (scene.cpp:161-163) that needs the pdf may
+//                then discard it.  The split between the populations follows the queue lengths; a wave whose
+//                queue has run dry takes chunks from the other queue's dynamic tail.
+//   shade(r)     per pixel of q_trace(r): finish the pending bounce (Mix::pdf, throughput, clamp hack), then
+//                attribute/texture fetch, Mix::sample, BRDF for the new hit; ends paths that miss / clamp /
+//                early-out (backward fold, next camera ray or pixel write) and queues the next ray.
 //
-// A pixel advances one bounce per round; spp * ray_depth rounds finish every pixel.  The two
-// traversal kernels are lean (few VGPRs, LDS stacks, all 64 lanes doing the same kind of work) and
-// keep their lanes busy by pulling the next ray as soon as one finishes; the two shading kernels run
-// with full waves.  Arithmetic is the same bit-exact code as the single-kernel path (rt_device.h).
+// A pixel advances one bounce per round; spp * ray_depth rounds finish every pixel.  The traversal loops are
+// lean (few VGPRs, LDS stacks, all 64 lanes doing the same kind of work) and keep their lanes busy by pulling
+// the next ray as soon as one finishes.  Arithmetic is the same bit-exact code as the single-kernel path.
 //
 // HBM layout per pixel slot: one 64-byte record (ray, hit, RNG, accumulator) followed by ray_depth 32-byte
 // stack entries, contiguous (256 B per slot at depth 6), so a scattered access still moves whole cache
@@ -27,9 +33,11 @@ namespace dev {
 
 // R0 record (4 x float4 per slot):
 //   q0 = o.xyz, d.x        q1 = d.y, d.z, rng_x, rng_saved
-//   q2 = t, u, v, hit      q3 = accum.xyz, packed{depth:4, has_saved:1, sample:27}
-// hit: 0xFFFFFFFF = miss, else triangle index | inside << 30.   After light(r), q2.x holds the light sum.
-// Stack entry (2 x float4): E0 = emission.xyz, pdf_partial   E1 = brdf (then mult).xyz, dot(d, n_s)
+//   q2 = t, u, v, hit      q3 = accum.xyz, packed{depth:4, has_saved:1, pending:1, sample:26}
+// hit: 0xFFFFFFFF = miss, else triangle index | inside << 30.  pending = the bounce at `depth` still waits for its
+// Mix::pdf / clamp step (its stack entry is filled, the ray in q0/q1 is the one it sampled).
+// Stack entry (2 x float4): E0 = emission.xyz, pdf (cosine + vndf terms; the light loop adds its term)
+//                           E1 = brdf (then mult).xyz, dot(d, n_s)
 struct WfView {
     float4 *r0;             // per slot: `stride` float4 = 4 (R0 record) + 2 per stack level, contiguous
     uint32_t stride;
@@ -46,7 +54,10 @@ RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0
 #define WF_INSIDE_BIT 0x40000000u
 #define WF_STACK 32            // LDS traversal stack entries per lane
 
-RT_DEV uint32_t wf_pack(int depth, bool has_saved, uint32_t sample) { return (uint32_t)depth | (has_saved ? 16u : 0u) | (sample << 5); }
+#define WF_PENDING_BIT 32u
+RT_DEV uint32_t wf_pack(int depth, bool has_saved, uint32_t sample, bool pending = false) {
+    return (uint32_t)depth | (has_saved ? 16u : 0u) | (pending ? WF_PENDING_BIT : 0u) | (sample << 6);
+}
 
 RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) {
     const int sub_x = R.tile_w >> 3, sub_per_tile = sub_x * (R.tile_h >> 3);
@@ -177,23 +188,29 @@ __global__ __launch_bounds__(256) void wf_init_kernel(SceneView S, RenderView R,
 #define WF_LEAF_BATCH 20
 #define WF_STEAL_CHUNK 64u
 struct WfSlice { uint32_t pos, end, dyn_base, dyn_end, chunk; uint32_t *head; bool done; };
-// The first (256 - dyn256)/256 of the queue is cut into one static slice per wave; the rest is handed out in
-// WF_STEAL_CHUNK pieces through one atomic counter to waves whose slice has run dry, which evens out the tail
-// (the slowest of ~4k static slices is ~20 % above the mean).
-RT_DEV WfSlice wf_slice(uint32_t count, uint32_t *head, int dyn256) {
-    uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    uint32_t chunk = (uint32_t)dyn256 >> 8;           // packed by the host: chunk << 8 | share
-    dyn256 &= 255;
-    uint32_t stat = (uint32_t)(((unsigned long long)count * (unsigned)(256 - dyn256)) >> 8);
+// The first (256 - share)/256 of a queue is cut into one static slice per wave of the population that owns the queue
+// (blocks [first_block, first_block + n_blocks)); the rest is handed out in chunks through one atomic counter to waves
+// whose slice has run dry — of either population — which evens out the tail (the slowest of ~4k static slices is ~20 %
+// above the mean).  `owner = false` gives a wave of the OTHER population an empty slice that can only steal.
+// dyn = chunk << 8 | share (packed by the host).
+RT_DEV WfSlice wf_slice(uint32_t count, uint32_t *head, int dyn, uint32_t first_block, uint32_t n_blocks, bool owner) {
+    uint32_t chunk = (uint32_t)dyn >> 8, share = (uint32_t)dyn & 255u;
+    uint32_t nwaves = n_blocks * (blockDim.x >> 6);
+    WfSlice s;
+    s.head = head; s.chunk = chunk ? chunk : WF_STEAL_CHUNK; s.dyn_end = count;
+    if (nwaves == 0) { s.pos = s.end = s.dyn_base = 0; s.done = count == 0; return s; } // nobody owns it: all of it is dynamic
+    uint32_t stat = (uint32_t)(((unsigned long long)count * (256u - share)) >> 8);
     uint32_t per = (stat + nwaves - 1) / nwaves;
     per = (per + 63u) & ~63u;
-    if (dyn256 == 0) stat = count;
-    else { stat = per * nwaves < count ? per * nwaves : count; }
-    WfSlice s;
-    s.pos = wid * per < stat ? wid * per : stat;
-    s.end = s.pos + per < stat ? s.pos + per : stat;
-    s.dyn_base = stat; s.dyn_end = count; s.head = head; s.chunk = chunk ? chunk : WF_STEAL_CHUNK;
+    stat = share == 0 ? count : (per * nwaves < count ? per * nwaves : count);
+    if (share == 0) { per = (count + nwaves - 1) / nwaves; per = (per + 63u) & ~63u; }
+    s.dyn_base = stat;
     s.done = stat >= count;
+    if (owner) {
+        uint32_t wid = (blockIdx.x - first_block) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        s.pos = wid * per < stat ? wid * per : stat;
+        s.end = s.pos + per < stat ? s.pos + per : stat;
+    } else s.pos = s.end = stat;
     return s;
 }
 // Wave-uniform: fetch the next dynamic chunk when the slice is empty.
@@ -219,12 +236,9 @@ RT_DEV bool wf_take(WfSlice &s, bool want, uint32_t &item) {
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters, int refill, int leaf_batch, int dyn256) {
-    __shared__ uint32_t lds_stack[4][WF_STACK][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t(*stack)[64] = lds_stack[wave];
-    const uint32_t *queue = W.q_trace[round & 1];
-    WfSlice slice = wf_slice(W.ctr[4 * round + 0], W.ctr + 4 * round + 2, dyn256);
+RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)[64], const uint32_t *queue, WfSlice slice,
+                          unsigned long long *counters, int refill, int leaf_batch) {
+    const int lane = threadIdx.x & 63;
     bool active = false;
     uint32_t slot = 0, cur = 0, hit = WF_MISS;
     int sp = 0;
@@ -308,13 +322,11 @@ __global__ __launch_bounds__(256) void wf_trace_kernel(SceneView S, WfView W, ui
 }
 
 // All-hits light sum (FiguresMix::getTotalPdf, distributions.h:148-165) with the reference's addition tree.
+// The finished sum goes straight into the pending bounce's pdf: E0.w += sum / n_lights (distributions.h:123,273).
 template <bool COUNT>
-__global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters, int refill, int leaf_batch, int dyn256) {
-    __shared__ uint32_t lds_stack[4][WF_STACK][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t(*stack)[64] = lds_stack[wave];
-    const uint32_t *queue = W.q_light;
-    WfSlice slice = wf_slice(W.ctr[4 * round + 1], W.ctr + 4 * round + 3, dyn256);
+RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)[64], const uint32_t *queue, WfSlice slice,
+                          unsigned long long *counters, int refill, int leaf_batch) {
+    const int lane = threadIdx.x & 63;
     bool active = false, descending = true;
     uint32_t slot = 0, cur = 0;
     int sp = 0;
@@ -358,7 +370,9 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
                     else if (h1) cur = c1;
                     else { v = 0.f; descending = false; }
                 } else if (sp == 0) { // sum complete
-                    reinterpret_cast<float *>(wf_rec(W, slot) + 2)[0] = v;
+                    int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
+                    float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
+                    *pdf = *pdf + v / (float)S.n_lights;
                     active = false;
                 } else {
                     --sp;
@@ -388,8 +402,35 @@ __global__ __launch_bounds__(256) void wf_light_kernel(SceneView S, WfView W, ui
     if (COUNT && counters) { atomicAdd(&counters[2], n_nodes); atomicAdd(&counters[3], n_tris); }
 }
 
-// ---- shade: scene.cpp:89-156 for every traced pixel of this round -----------------------------------------------
-RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, const Pusher &to_light, const Pusher &next) {
+// ---- traverse: both loops in one persistent launch -------------------------------------------------------------------
+// Blocks [0, nb_t) own the trace queue, the rest own the light queue; nb_t follows the queue lengths weighted by the
+// measured cost of one query of each kind (a light query costs ~7/6 of a closest-hit query on the benchmark scene).
+// After its own queue a block helps with the other one's dynamic tail, so a wrong split only costs a few chunks.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void wf_traverse_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters,
+                                                          int t_refill, int t_batch, int l_refill, int l_batch, int dyn) {
+    __shared__ uint32_t lds_stack[4][WF_STACK][64];
+    uint32_t(*stack)[64] = lds_stack[threadIdx.x >> 6];
+    const uint32_t ct = W.ctr[4 * round + 0], cl = S.n_lights ? W.ctr[4 * round + 1] : 0u;
+    const uint32_t nb = gridDim.x;
+    uint32_t nb_t = nb;
+    if (cl) {
+        unsigned long long wt = 6ull * ct, wl = 7ull * cl;
+        nb_t = (uint32_t)((wt * nb + (wt + wl) / 2) / (wt + wl));
+        if (nb_t < 1u) nb_t = 1u;
+        if (nb_t > nb - 1u) nb_t = nb - 1u;
+    }
+    const uint32_t *q_t = W.q_trace[round & 1], *q_l = W.q_light;
+    uint32_t *head_t = W.ctr + 4 * round + 2, *head_l = W.ctr + 4 * round + 3;
+    const bool tracer = blockIdx.x < nb_t;
+    if (tracer) wf_trace_loop<COUNT>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, true), counters, t_refill, t_batch);
+    if (cl) wf_light_loop<COUNT>(S, W, stack, q_l, wf_slice(cl, head_l, dyn, nb_t, nb - nb_t, !tracer), counters, l_refill, l_batch);
+    if (!tracer) wf_trace_loop<COUNT>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, false), counters, t_refill, t_batch);
+}
+
+// ---- shade: finish the pending bounce (scene.cpp:158-164), then scene.cpp:89-156 for the new hit ------------------------
+RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, const Pusher &to_light, const Pusher &next,
+                          unsigned long long *counters) {
     float4 *r = wf_rec(W, slot);
     float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
     F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
@@ -397,8 +438,30 @@ RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView 
     uint32_t packed = __float_as_uint(q3.w);
     int depth = (int)(packed & 15u);
     rng.has_saved = (packed & 16u) != 0;
-    uint32_t sample = packed >> 5;
+    uint32_t sample = packed >> 6;
     F3 accum = f3(q3.x, q3.y, q3.z);
+    if (packed & WF_PENDING_BIT) {
+        // The bounce at `depth` sampled the ray that was just traced; its pdf is complete now (Mix::pdf, distributions.h:268-278).
+        float4 *e = wf_entry(W, slot, depth);
+        float4 e0 = e[0], e1 = e[1];
+        F3 emission = f3(e0.x, e0.y, e0.z), brdf = f3(e1.x, e1.y, e1.z);
+        float pdf = e0.w / (float)S.n_components;                              // :278
+        float k = (float)(1. / (double)pdf * fabs((double)e1.w));              // scene.cpp:159
+        F3 mult = k * brdf;
+        bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
+        if (clamp || depth + 1 >= R.ray_depth) {
+            // clamp hack (scene.cpp:161-163): the path returns the emission and the speculative hit is dropped; at the
+            // last level the inner call returns 0, i.e. emission + mult * 0 evaluated literally.
+            if (counters) atomicAdd(&counters[10], 1ull);
+            F3 tail = emission;
+            int levels = depth;
+            if (!clamp) { e[1] = make_float4(mult.x, mult.y, mult.z, e1.w); tail = f3(0.f, 0.f, 0.f); levels = depth + 1; }
+            wf_finish_path(S, R, W, slot, levels, tail, accum, rng, sample, next);
+            return;
+        }
+        e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
+        depth++;
+    }
     uint32_t hit = __float_as_uint(q2.w);
     if (hit == WF_MISS) { wf_finish_path(S, R, W, slot, depth, miss_color(S, d), accum, rng, sample, next); return; }
     HitRec h;
@@ -438,12 +501,12 @@ RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView 
     e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sh.sn));
     r[0] = make_float4(xo.x, xo.y, xo.z, nd.x);                           // the next ray doubles as the light query
     r[1] = make_float4(nd.y, nd.z, __uint_as_float(rng.x), rng.saved);
-    r[2] = make_float4(0.f, q2.y, q2.z, q2.w);                            // light sum slot (stays 0 without lights)
-    r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(depth, rng.has_saved, sample)));
-    wf_push(to_light, slot);
+    r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(depth, rng.has_saved, sample, true)));
+    wf_push(next, slot);                                                   // traced speculatively next round ...
+    if (S.n_lights) wf_push(to_light, slot);                               // ... beside its own light-pdf sum
 }
 
-__global__ __launch_bounds__(256) void wf_shade_kernel(SceneView S, RenderView R, WfView W, uint32_t round) {
+__global__ __launch_bounds__(256) void wf_shade_kernel(SceneView S, RenderView R, WfView W, uint32_t round, unsigned long long *counters) {
     __shared__ uint32_t buf_l[WF_BUF], buf_n[WF_BUF];
     __shared__ uint32_t cnt_l, cnt_n, gbase;
     if (threadIdx.x == 0) { cnt_l = 0; cnt_n = 0; }
@@ -452,67 +515,16 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(SceneView S, RenderView R
     Pusher next; next.buf = buf_n; next.cnt = &cnt_n;
     const uint32_t *queue = W.q_trace[round & 1];
     const uint32_t count = W.ctr[4 * round + 0];
-    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + 4 * (round + 1) + 0;
+    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + 4 * (round + 1) + 0, *light_count = W.ctr + 4 * (round + 1) + 1;
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t i = base + threadIdx.x;
-        if (i < count) wf_shade_item(S, R, W, queue[i], to_light, next);
+        if (i < count) wf_shade_item(S, R, W, queue[i], to_light, next, counters);
         __syncthreads();
-        if (cnt_l > WF_BUF - 256) wf_flush(to_light, W.q_light, W.ctr + 4 * round + 1, &gbase);
+        if (cnt_l > WF_BUF - 256) wf_flush(to_light, W.q_light, light_count, &gbase);
         if (cnt_n > WF_BUF - 256) wf_flush(next, next_queue, next_count, &gbase);
     }
     __syncthreads();
-    wf_flush(to_light, W.q_light, W.ctr + 4 * round + 1, &gbase);
-    wf_flush(next, next_queue, next_count, &gbase);
-}
-
-// ---- update: scene.cpp:158-164 for every pixel that reached the pdf stage -----------------------------------------
-RT_DEV void wf_update_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, const Pusher &next) {
-    float4 *r = wf_rec(W, slot);
-    float4 q1 = r[1], q2 = r[2], q3 = r[3];
-    uint32_t packed = __float_as_uint(q3.w);
-    int depth = (int)(packed & 15u);
-    uint32_t sample = packed >> 5;
-    F3 accum = f3(q3.x, q3.y, q3.z);
-    float4 *e = wf_entry(W, slot, depth);
-    float4 e0 = e[0], e1 = e[1];
-    F3 emission = f3(e0.x, e0.y, e0.z), brdf = f3(e1.x, e1.y, e1.z);
-    float pdf = e0.w;
-    if (S.n_components == 3) pdf += q2.x / (float)S.n_lights;             // distributions.h:123,273
-    pdf = pdf / (float)S.n_components;                                     // :278
-    float k = (float)(1. / (double)pdf * fabs((double)e1.w));              // scene.cpp:159
-    F3 mult = k * brdf;
-    bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
-    if (clamp || depth + 1 >= R.ray_depth) {
-        // clamp hack (scene.cpp:161-163): the path returns the emission; at the last level the inner call
-        // returns 0, i.e. emission + mult * 0 evaluated literally.
-        Rng rng; rng.x = __float_as_uint(q1.z); rng.saved = q1.w; rng.has_saved = (packed & 16u) != 0;
-        F3 tail = emission;
-        int levels = depth;
-        if (!clamp) { e[1] = make_float4(mult.x, mult.y, mult.z, e1.w); tail = f3(0.f, 0.f, 0.f); levels = depth + 1; }
-        wf_finish_path(S, R, W, slot, levels, tail, accum, rng, sample, next);
-    } else {
-        e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
-        r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float((packed & ~15u) | (uint32_t)(depth + 1)));
-        wf_push(next, slot);
-    }
-}
-
-__global__ __launch_bounds__(256) void wf_update_kernel(SceneView S, RenderView R, WfView W, uint32_t round) {
-    __shared__ uint32_t buf_n[WF_BUF];
-    __shared__ uint32_t cnt_n, gbase;
-    if (threadIdx.x == 0) cnt_n = 0;
-    __syncthreads();
-    Pusher next; next.buf = buf_n; next.cnt = &cnt_n;
-    const uint32_t *queue = W.q_light;
-    const uint32_t count = W.ctr[4 * round + 1];
-    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + 4 * (round + 1) + 0;
-    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
-        uint32_t i = base + threadIdx.x;
-        if (i < count) wf_update_item(S, R, W, queue[i], next);
-        __syncthreads();
-        if (cnt_n > WF_BUF - 256) wf_flush(next, next_queue, next_count, &gbase);
-    }
-    __syncthreads();
+    wf_flush(to_light, W.q_light, light_count, &gbase);
     wf_flush(next, next_queue, next_count, &gbase);
 }
 

@@ -348,11 +348,17 @@ size_t rt_output_elems(const rt_render_params *p) {
     return (size_t)R.width * R.height * 3;
 }
 
-// Wavefront driver: spp * ray_depth rounds of trace / shade / light / update (device/rt_wavefront.h).
+// Rounds a pixel needs per camera sample: one per bounce; without the deepest-level shortcut the last bounce's pdf / clamp
+// step takes one more.
+static size_t wavefront_rounds(const rt_scene *scene, const RenderView &R) {
+    return (size_t)R.samples * ((size_t)R.ray_depth + (scene->view.last_level_emission_only ? 0u : 1u));
+}
+
+// Wavefront driver: per round one traverse launch and one shade launch (device/rt_wavefront.h).
 // No host synchronisation inside: queue lengths live in device memory, one counter block per round.
 static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     const size_t n_slots = (size_t)n_work * 64;
-    const size_t rounds = (size_t)R.samples * R.ray_depth;
+    const size_t rounds = wavefront_rounds(scene, R);
     if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_rounds < rounds) {
         scene->free_wf();
         auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); scene->wf_allocs.push_back(p); return p; };
@@ -383,13 +389,10 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     if (time_trace) while (scene->ev_pool.size() < 2 * rounds) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r], stream));
-        if (count) hipLaunchKernelGGL(dev::wf_trace_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, dyn256);
-        else hipLaunchKernelGGL(dev::wf_trace_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, dyn256);
+        if (count) hipLaunchKernelGGL(dev::wf_traverse_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
+        else hipLaunchKernelGGL(dev::wf_traverse_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r + 1], stream));
-        hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
-        if (count) hipLaunchKernelGGL(dev::wf_light_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch, dyn256);
-        else hipLaunchKernelGGL(dev::wf_light_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, l_refill, l_batch, dyn256);
-        hipLaunchKernelGGL(dev::wf_update_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r);
+        hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r, ctrs);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -459,7 +462,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (blocks) {
             if (use_wavefront) {
                 launch_wavefront(scene, R, n_work, stream, count, stats != nullptr);
-                launches = 1 + 4 * (uint32_t)R.samples * (uint32_t)R.ray_depth;
+                launches = 1 + 2 * (uint32_t)wavefront_rounds(scene, R);
             } else if (p->integrator == RT_INTEGRATOR_HW1) {
                 uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
                 hipLaunchKernelGGL(dev::render_hw1_kernel, dim3((npx + 255) / 256), dim3(256), 0, stream, scene->viewt, R.width, R.height, txt_tan_fov_y, d_rgb, d_rgb8);
@@ -499,10 +502,11 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 128, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
-            size_t rounds = (size_t)R.samples * R.ray_depth;
+            size_t rounds = wavefront_rounds(scene, R);
             std::vector<uint32_t> ctr((rounds + 2) * 4);
             HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
             for (size_t r = 0; r < rounds; r++) { h_cnt[0] += ctr[4 * r]; if (scene->info.n_lights) h_cnt[1] += ctr[4 * r + 1]; }
+            h_cnt[0] -= h_cnt[10]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
         }
         if (count && getenv("RTAMD_DEBUG_COUNTERS"))
             fprintf(stderr, "[rtamd] trace kernel: wave node-iterations %llu, leaf phases %llu (lanes %llu), refills %llu; lane node visits %llu, tri tests %llu\n",
@@ -517,7 +521,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
             if (use_wavefront && blocks) {
-                size_t rounds = (size_t)R.samples * R.ray_depth;
+                size_t rounds = wavefront_rounds(scene, R);
                 double sum = 0;
                 for (size_t r = 0; r < rounds; r++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * r], scene->ev_pool[2 * r + 1])); sum += e; }
                 stats->dominant_kernel_ms = sum; stats->dominant_kernel_launches = (uint32_t)rounds;

@@ -158,19 +158,23 @@ def main():
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         samples_per_render = st.samples  # this rank's share
         render_gbs = bps * samples_per_render / (k_ms * 1e-3) / 1e9
-        # Dominant kernel = wf_trace_kernel (closest-hit traversal; ~41 % of GPU time, profiles/).  Its algorithmic
-        # bytes per query are the root-to-leaf part of SURVEY 8(d): (ceil(log2 N_tri)+1) nodes x 32 B + 36 B positions.
+        # Dominant kernel = wf_traverse_kernel (closest-hit + light-sum traversal in one persistent launch; ~73 % of GPU
+        # time, profiles/).  Its algorithmic bytes are the root-to-leaf parts of SURVEY 8(d): per closest-hit query
+        # (ceil(log2 N_tri)+1) nodes x 32 B + 36 B positions, per light-pdf query the same with N_light.
         wavefront = st.dominant_kernel_launches > 1
         q_bytes = (math.ceil(math.log2(max(info.n_triangles, 2))) + 1) * 32 + 36
+        lq_bytes = (math.ceil(math.log2(max(info.n_lights, 2))) + 1) * 32 + 36
         n_l = max(1, sum(dom_launches))
         launch_ms = sum(dom_ms) / n_l                                      # average launch duration, HIP events on the launch stream
         queries_per_launch = s_bar * samples_per_render * len(dom_ms) / n_l
-        achieved = (q_bytes * queries_per_launch / (launch_ms * 1e-3) / 1e9) if wavefront else render_gbs
+        light_queries_per_launch = p_bar * samples_per_render * len(dom_ms) / n_l
+        achieved = ((q_bytes * queries_per_launch + lq_bytes * light_queries_per_launch) / (launch_ms * 1e-3) / 1e9) if wavefront else render_gbs
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                    "kernel": "wf_trace_kernel" if wavefront else "render_hw8_kernel",
+                    "kernel": "wf_traverse_kernel" if wavefront else "render_hw8_kernel",
                     "kernel_avg_launch_ms": round(launch_ms, 4), "kernel_launches_per_step": int(n_l / max(1, len(dom_ms))),
                     "kernel_bytes_per_query": q_bytes, "queries_per_launch": round(queries_per_launch, 1),
+                    "kernel_bytes_per_light_query": lq_bytes, "light_queries_per_launch": round(light_queries_per_launch, 1),
                     "whole_render": {"achieved": round(render_gbs, 3), "frac": round(render_gbs / HBM_PEAK_GBS, 6), "gpu_ms": round(k_ms, 3),
                                      "bytes_per_sample": round(bps, 1)},
                     "s_bar": round(s_bar, 3), "p_bar": round(p_bar, 3),

@@ -19,7 +19,7 @@ import sys
 
 def main():
     root, workload, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    kernel = "wf_trace_kernel"
+    kernel = "wf_traverse_kernel"
     tot = {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]}
     for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):

@@ -194,7 +194,7 @@ struct WfSlice { uint32_t pos, end, dyn_base, dyn_end, chunk; uint32_t *head; bo
 // above the mean).  `owner = false` gives a wave of the OTHER population an empty slice that can only steal.
 // dyn = chunk << 8 | share (packed by the host).
 RT_DEV WfSlice wf_slice(uint32_t count, uint32_t *head, int dyn, uint32_t first_block, uint32_t n_blocks, bool owner) {
-    uint32_t chunk = (uint32_t)dyn >> 8, share = (uint32_t)dyn & 255u;
+    uint32_t chunk = ((uint32_t)dyn >> 8) & 255u, share = (uint32_t)dyn & 255u;
     uint32_t nwaves = n_blocks * (blockDim.x >> 6);
     WfSlice s;
     s.head = head; s.chunk = chunk ? chunk : WF_STEAL_CHUNK; s.dyn_end = count;
@@ -404,7 +404,7 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
 
 // ---- traverse: both loops in one persistent launch -------------------------------------------------------------------
 // Blocks [0, nb_t) own the trace queue, the rest own the light queue; nb_t follows the queue lengths weighted by the
-// measured cost of one query of each kind (a light query costs ~7/6 of a closest-hit query on the benchmark scene).
+// measured cost of one query of each kind (a light query costs ~7/5 of a closest-hit query on the benchmark scene).
 // After its own queue a block helps with the other one's dynamic tail, so a wrong split only costs a few chunks.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void wf_traverse_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters,
@@ -415,7 +415,9 @@ __global__ __launch_bounds__(256) void wf_traverse_kernel(SceneView S, WfView W,
     const uint32_t nb = gridDim.x;
     uint32_t nb_t = nb;
     if (cl) {
-        unsigned long long wt = 6ull * ct, wl = 7ull * cl;
+        unsigned long long kt = ((uint32_t)dyn >> 16) & 255u, kl = (uint32_t)dyn >> 24;  // cost weights packed by the host (0 = default 5 : 7, measured best on the benchmark scene)
+        if (!kt || !kl) { kt = 5; kl = 7; }
+        unsigned long long wt = kt * ct, wl = kl * cl;
         nb_t = (uint32_t)((wt * nb + (wt + wl) / 2) / (wt + wl));
         if (nb_t < 1u) nb_t = 1u;
         if (nb_t > nb - 1u) nb_t = nb - 1u;
@@ -506,7 +508,10 @@ RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView 
     if (S.n_lights) wf_push(to_light, slot);                               // ... beside its own light-pdf sum
 }
 
-__global__ __launch_bounds__(256) void wf_shade_kernel(SceneView S, RenderView R, WfView W, uint32_t round, unsigned long long *counters) {
+#ifndef WF_SHADE_OCC
+#define WF_SHADE_OCC 3          // measured: 3 resident blocks per CU (some spills) beats the unconstrained 2 by ~1.5 %
+#endif
+__global__ __launch_bounds__(256, WF_SHADE_OCC) void wf_shade_kernel(SceneView S, RenderView R, WfView W, uint32_t round, unsigned long long *counters) {
     __shared__ uint32_t buf_l[WF_BUF], buf_n[WF_BUF];
     __shared__ uint32_t cnt_l, cnt_n, gbase;
     if (threadIdx.x == 0) { cnt_l = 0; cnt_n = 0; }

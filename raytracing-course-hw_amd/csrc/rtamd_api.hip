@@ -378,7 +378,8 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     const uint32_t persistent_blocks = (uint32_t)scene->n_cus * blocks_per_cu;
     int dyn256 = 64;                                                   // share of each queue (of 256) handed out dynamically at the tail
     if (const char *e = getenv("RTAMD_WF_DYNAMIC_256")) dyn256 = atoi(e) < 0 ? 0 : (atoi(e) > 255 ? 255 : atoi(e));
-    if (const char *e = getenv("RTAMD_WF_STEAL_CHUNK")) dyn256 |= (atoi(e) > 0 ? atoi(e) : 64) << 8; // tuning: items per dynamic chunk (default 64)
+    if (const char *e = getenv("RTAMD_WF_STEAL_CHUNK")) dyn256 |= ((atoi(e) > 0 ? atoi(e) : 64) & 255) << 8; // tuning: items per dynamic chunk (default 64)
+    if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) dyn256 |= (a << 16) | (b << 24); } // cost weights closest-hit : light query
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
     const int t_refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL), t_batch = env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH);
     const int l_refill = env_int("RTAMD_LIGHT_REFILL", WF_REFILL), l_batch = env_int("RTAMD_LIGHT_LEAF_BATCH", WF_LEAF_BATCH);

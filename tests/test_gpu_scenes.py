@@ -53,6 +53,42 @@ def test_textured_room_matches_oracle(rt, small_room, kernel):
     scene.close()
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_shallow_ray_depths_match_oracle(rt, small_room, depth):
+    """RAY_DEPTH 1..3: the deepest-level shortcut, the pending pdf/clamp step and the speculative trace all sit on the
+    very first rounds."""
+    scene = rt.Scene(small_room)
+    rgb, rgb8, _ = scene.render(96, 54, 9, ray_depth=depth)
+    ref, ref8, _ = oracle_lib.Hw8Oracle(small_room).render(96, 54, 9, ray_depth=depth)
+    rmse, bad = _report(f"room depth {depth}", rgb, ref, rgb8, ref8)
+    assert ref.mean() > 0.005 and rmse < RMSE_TOL and bad <= 3
+    scene.close()
+
+
+def test_without_the_deepest_level_shortcut_the_pixels_are_the_same(rt, small_room, monkeypatch):
+    """RTAMD_NO_LAST_LEVEL_SHORTCUT=1 makes the wavefront path do the full arithmetic at the last level (one more round per
+    sample: its pdf / clamp step follows a speculative trace that is always discarded); a material outside the shortcut's
+    precondition (metallicFactor > 1) switches it off by itself.  Both must give the oracle's pixels."""
+    ref, ref8, _ = oracle_lib.Hw8Oracle(small_room).render(96, 54, 7)
+    monkeypatch.setenv("RTAMD_NO_LAST_LEVEL_SHORTCUT", "1")
+    scene = rt.Scene(small_room)
+    rgb, rgb8, st = scene.render(96, 54, 7)
+    monkeypatch.delenv("RTAMD_NO_LAST_LEVEL_SHORTCUT")
+    rmse, bad = _report("room, shortcut off", rgb, ref, rgb8, ref8)
+    assert st.launches == 1 + 2 * 7 * 7 and rmse < RMSE_TOL and bad <= 3
+    scene.close()
+    import copy
+    sd = pin_cases.random_triangle_scene(n=300, seed=5)
+    sd.materials[0].metallic_factor = 1.5
+    sd._build_desc()
+    scene = rt.Scene(sd)
+    rgb, rgb8, st = scene.render(64, 48, 5)
+    ref, ref8, _ = oracle_lib.Hw8Oracle(sd).render(64, 48, 5)
+    rmse, bad = _report("soup with metallicFactor 1.5", rgb, ref, rgb8, ref8)
+    assert st.launches == 1 + 2 * 5 * 7 and rmse < RMSE_TOL and bad <= 3
+    scene.close()
+
+
 def test_triangle_soup_with_ties_matches_oracle(rt, kernel):
     sd = pin_cases.random_triangle_scene(n=600, seed=3)
     scene = rt.Scene(sd)

@@ -215,7 +215,8 @@ const rt_scene_desc *rt_host_scene_desc(const rt_host_scene *hs);
 void rt_host_scene_free(rt_host_scene *hs);
 /* Binary PPM writer (hw8/src/sceneio.cpp:383-385,397-401). */
 int rt_write_ppm(const char *path, int32_t width, int32_t height, const uint8_t *rgb8);
-/* PNG (8-bit gray/RGB/RGBA/palette, non-interlaced) decode to 3-channel RGB; caller frees with rt_free. */
+/* Image file -> 3-channel RGB8 like stbi_load(path, ..., 3): PNG (8-bit gray/RGB/RGBA/palette, non-interlaced) or
+ * baseline JPEG (grayscale / YCbCr, 1x or 2x chroma subsampling), chosen by magic bytes; caller frees with rt_free. */
 int rt_decode_png(const char *path, int32_t *width, int32_t *height, uint8_t **rgb);
 void rt_free(void *p);
 

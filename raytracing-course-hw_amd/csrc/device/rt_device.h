@@ -265,8 +265,8 @@ RT_DEV float light_pdf_one(const LightRec *L, F3 x, F3 d, bool &last) {
     if (!tri_test(T, x, d, t, u, v, inside)) return 0.f;
     // (t cannot be NaN here: tri_test requires t > 0; distributions.h:141-143 is dead code)
     const float4 *q = reinterpret_cast<const float4 *>(L) + 3;
-    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    // q0 = b.xyz c.x | q1 = c.yz point_prob n3.x | q2 = n3.yz dn1.xy | q3 = dn1.z dn2.xyz
+    float4 q1 = q[1], q2 = q[2], q3 = q[3];
+    // (q[0] = b.xyz c.x, used by the sampler only) | q1 = c.yz point_prob n3.x | q2 = n3.yz dn1.xy | q3 = dn1.z dn2.xyz
     float point_prob = q1.z;
     F3 n3 = f3(q1.w, q2.x, q2.y), dn1 = f3(q2.z, q2.w, q3.x), dn2 = f3(q3.y, q3.z, q3.w);
     F3 sn = n3 + u * dn1 + v * dn2;           // primitives.cpp:110

@@ -252,9 +252,8 @@ std::vector<uint8_t> read_file(const std::string &path) {
 
 void load_image_rgb8(const std::string &path, int &width, int &height, std::vector<uint8_t> &rgb) {
     std::vector<uint8_t> file = read_file(path);
-    if (file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8)
-        throw std::runtime_error("JPEG textures are not supported (" + path + ")");
-    decode_png(file, width, height, rgb);
+    if (file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8) decode_jpeg(file, width, height, rgb);
+    else decode_png(file, width, height, rgb);
 }
 
 } // namespace rtamd

@@ -23,10 +23,10 @@ extern "C" {
 int rtt_logf(const float *in, float *out, size_t n) {
     float *d_in = nullptr, *d_out = nullptr;
     if (hipMalloc((void **)&d_in, n * 4) != hipSuccess || hipMalloc((void **)&d_out, n * 4) != hipSuccess) return -1;
-    hipMemcpy(d_in, in, n * 4, hipMemcpyHostToDevice);
+    if (hipMemcpy(d_in, in, n * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_in); (void)hipFree(d_out); return -2; }
     hipLaunchKernelGGL(k_logf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, d_out, n);
     int rc = hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
-    hipFree(d_in); hipFree(d_out);
+    (void)hipFree(d_in); (void)hipFree(d_out);
     return rc;
 }
 // streams for seeds seed0 .. seed0+n_seeds-1: n_u uniforms then n_n normals each
@@ -36,7 +36,7 @@ int rtt_rng_streams(uint32_t seed0, int n_seeds, int n_u, int n_n, float *out) {
     if (hipMalloc((void **)&d_out, n * 4) != hipSuccess) return -1;
     hipLaunchKernelGGL(k_rng, dim3((n_seeds + 63) / 64), dim3(64), 0, 0, seed0, n_seeds, n_u, n_n, d_out);
     int rc = hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
-    hipFree(d_out);
+    (void)hipFree(d_out);
     return rc;
 }
 }

@@ -123,3 +123,27 @@ def test_gltf_interleaved_vertex_buffer_and_u8_indices_load_like_the_tight_layou
     assert a.positions.shape == b.positions.shape == (16, 9)
     for name in ("positions", "normals", "texcoords", "tangents"):
         assert np.array_equal(getattr(a, name).view(np.uint32), getattr(b, name).view(np.uint32)), name
+
+
+def test_jpeg_textures_decode_close_to_libjpeg(rt, tmp_path):
+    """Extension: baseline JPEG textures.  The decoder follows stb_image's pipeline (the reference's
+    loader), which is not available here, so its texel bytes are PARITY UNPINNED; this test only checks it against libjpeg
+    (PIL) on 4:4:4 / 4:2:2 / 4:2:0 / restart-interval / grayscale files: IDCT and chroma-filter rounding may differ by a
+    few levels, nothing more."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:93, 0:130]
+    img = np.stack([128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 13.0), 128 + 90 * np.cos(xx / 17.0 + yy / 5.0), 40 + yy * 2], axis=2).clip(0, 255).astype(np.uint8)
+    img[20:40, 30:60] = rng.integers(0, 255, (20, 30, 3))
+    cases = [("444", dict(quality=95, subsampling=0), 3), ("422", dict(quality=90, subsampling=1), 8), ("420", dict(quality=85, subsampling=2), 3),
+             ("420_restart", dict(quality=60, subsampling=2, restart_marker_blocks=4), 3), ("gray", dict(quality=92), 2)]
+    for name, kw, tol in cases:
+        path = str(tmp_path / f"{name}.jpg")
+        Image.fromarray(img[:, :, 0] if name == "gray" else img).save(path, "JPEG", **kw)
+        mine = rt.decode_png(path)
+        ref = np.asarray(Image.open(path).convert("RGB"))
+        d = np.abs(mine.astype(int) - ref.astype(int))
+        assert mine.shape == ref.shape and d.max() <= tol and d.mean() < 0.3, (name, int(d.max()), float(d.mean()))
+    Image.fromarray(img).save(str(tmp_path / "prog.jpg"), "JPEG", progressive=True)
+    with pytest.raises(rt.RtError):
+        rt.decode_png(str(tmp_path / "prog.jpg"))

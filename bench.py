@@ -213,7 +213,7 @@ def main():
         result = {"metric": "Msamples/sec at 1920x1080x256spp" if headline else f"Msamples/sec ({args.workload}, spp={SPP}; NOT the headline config)",
                   "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-                  "scaling": "strong" if (world == 1 or args.scaling == "strong") else "weak",
+                  "scaling": args.scaling,
                   "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "config": {"workload": args.workload if (W, H) == (base_w, base_h) else f"{args.workload} grown to {W}x{H} ({world} x {base_w}x{base_h} pixels)", "scene": "synth_room_v1 (seed 20241223)", "triangles": int(info.n_triangles),
                              "emissive_triangles": int(info.n_lights), "width": W, "height": H, "spp": SPP, "ray_depth": 6,

@@ -139,7 +139,7 @@ def test_render_is_deterministic_and_idempotent(rt, small_room):
 
 
 def test_full_config_1920x1080x256_crops_match_oracle(rt, tmp_path):
-    """BASELINE.json configs[3] at full size: the whole frame is rendered on the GPU; the oracle replays three
+    """BASELINE.json configs[3] at full size: the whole frame is rendered on the GPU; the oracle replays eight
     32x32 crops of it (it would need hours for the frame).  Also: prefix property — rendering the frame with the
     megakernel organisation gives the same bytes on one crop-sized sub-shard."""
     import gen_synth_room
@@ -152,7 +152,7 @@ def test_full_config_1920x1080x256_crops_match_oracle(rt, tmp_path):
     assert np.isfinite(rgb).all() and rgb.mean() > 0.05
     orc = oracle_lib.Hw8Oracle(sd)
     worst = 0.0
-    for (x0, y0) in ((944, 524), (64, 900), (1700, 96)):
+    for (x0, y0) in ((944, 524), (64, 900), (1700, 96), (400, 300), (1300, 700), (0, 0), (1888, 1048), (960, 40)):
         ref, ref8, _ = orc.render(1920, 1080, 256, rect=(x0, y0, 32, 32))
         crop, crop8 = rgb[y0:y0 + 32, x0:x0 + 32], rgb8[y0:y0 + 32, x0:x0 + 32]
         rmse, bad = _report(f"1080p crop ({x0},{y0})", crop, ref, crop8, ref8)

@@ -494,5 +494,18 @@ RT_DEV uint8_t tonemap1(float x) {
     return (uint8_t)round((double)(255 * g));
 }
 
+// Pixel slot -> pixel: slots run through the 8x8 sub-tiles of this shard's tiles (slot >> 6 = sub-tile, slot & 63 = pixel in it).
+RT_DEV void slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) {
+    const int sub_x = R.tile_w >> 3, sub_per_tile = sub_x * (R.tile_h >> 3);
+    uint32_t w = slot >> 6, lane = slot & 63u;
+    uint32_t st = w / sub_per_tile, sub = w % sub_per_tile;
+    uint32_t gt = R.shard_count > 1 ? (uint32_t)R.shard_index + st * (uint32_t)R.shard_count : st;
+    int tx0 = (int)(gt % (uint32_t)R.tiles_x) * R.tile_w, ty0 = (int)(gt / (uint32_t)R.tiles_x) * R.tile_h;
+    int lx = (int)(sub % sub_x) * 8 + (int)(lane & 7), ly = (int)(sub / sub_x) * 8 + (int)(lane >> 3);
+    x = tx0 + lx; y = ty0 + ly;
+    inside = x < R.width && y < R.height;
+    out_index = R.shard_count > 1 ? ((size_t)st * R.tile_h + ly) * R.tile_w + lx : (size_t)y * R.width + x;
+}
+
 } // namespace dev
 } // namespace rtamd

@@ -143,14 +143,24 @@ struct Frame6 {
     int kind; bool inside; float ior;
 };
 
-// Scene::getColor of hw6 as an explicit stack machine.
-RT_DEV F3 trace_tree6(const SceneView6 &S, int ray_depth, Rng &rng, F3 o, F3 d, uint32_t *stack) {
+// Scene::getColor of hw6 as an explicit stack machine that advances ONE step per call (one closest-hit + shading, or one
+// return step), so the lanes of a wave can sit at different samples and pixels: a lane whose path ends starts its next
+// camera sample at once instead of idling until the longest path of the wave has finished.
+struct Machine6 {
     Frame6 frames[RT6_MAX_DEPTH];
-    int fp = 0;
+    int fp;
+    bool evaluating; // true: evaluate getColor(o, d, ray_depth - fp) ; false: `ret` is a finished child value
+    F3 o, d, ret;
+};
+RT_DEV void machine6_start(Machine6 &M, F3 o, F3 d) { M.fp = 0; M.evaluating = true; M.o = o; M.d = d; M.ret = f3(0.f, 0.f, 0.f); }
+// Returns true when the path is complete (M.ret = getColor of the camera ray).
+RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6 &M, uint32_t *stack) {
+    Frame6 *frames = M.frames;
+    int &fp = M.fp;
     const float epsf = 9.99999974737875163555e-05f; // (float)1e-4L
-    F3 ret = f3(0.f, 0.f, 0.f);
-    bool evaluating = true; // true: evaluate getColor(o, d, ray_depth - fp) ; false: `ret` is a finished child value
-    for (;;) {
+    F3 &ret = M.ret, &o = M.o, &d = M.d;
+    bool &evaluating = M.evaluating;
+    do {
         if (evaluating) {
             if (fp >= ray_depth) { ret = f3(0.f, 0.f, 0.f); evaluating = false; continue; }   // recLimit == 0
             Hit6 h = closest_hit6(S, o, d, stack);
@@ -195,7 +205,7 @@ RT_DEV F3 trace_tree6(const SceneView6 &S, int ray_depth, Rng &rng, F3 o, F3 d, 
                 o = x + epsf * refl; d = refl;                                                  // scene.cpp:72,76
             }
         } else {
-            if (fp == 0) break;
+            if (fp == 0) return true;
             Frame6 &f = frames[--fp];
             if (f.kind == F6_MUL) { ret = f.emission + f.mult * ret; continue; }                // scene.cpp:69,73
             if (f.kind == F6_DIEL_REFRACT) {                                                    // scene.cpp:99-103
@@ -224,47 +234,62 @@ RT_DEV F3 trace_tree6(const SceneView6 &S, int ray_depth, Rng &rng, F3 o, F3 d, 
             evaluating = true;
             continue;
         }
-    }
-    return ret;
+    } while (false);
+    return false;
 }
 
 __global__ __launch_bounds__(64) void render_hw6_kernel(SceneView6 S, RenderView R, uint32_t n_work) {
     uint32_t stack[RT6_STACK_SIZE];
     const int lane = threadIdx.x & 63;
-    const int sub_x = R.tile_w >> 3, sub_per_tile = sub_x * (R.tile_h >> 3);
+    const uint32_t n_slots = n_work * 64u;   // pixel slots in the tile order of slot_to_pixel()
+    Machine6 M;
+    machine6_start(M, f3(0.f, 0.f, 0.f), f3(0.f, 0.f, 1.f));
+    Rng rng; rng_seed(rng, 0u);
+    F3 color = f3(0.f, 0.f, 0.f);
+    int x = 0, y = 0, s = 0;
+    size_t out_index = 0;
+    bool have_pixel = false, exhausted = false;
+    auto camera_ray = [&]() {                                                                    // scene.cpp:111-126 (direction not normalised)
+        float nx = (float)x + rng_u01(rng);
+        float ny = (float)y + rng_u01(rng);
+        float cx = R.tan_fov_x * (2 * nx / (float)R.width - 1);
+        float cy = S.tan_fov_y * (2 * ny / (float)R.height - 1);
+        machine6_start(M, f3(S.cam_pos), cx * f3(S.cam_right) - cy * f3(S.cam_up) + f3(S.cam_fwd));
+    };
     for (;;) {
-        uint32_t w = 0;
-        if (lane == 0) w = atomicAdd(R.work_counter, 1u);
-        w = __shfl(w, 0);
-        if (w >= n_work) break;
-        uint32_t st = w / sub_per_tile, sub = w % sub_per_tile;
-        uint32_t gt = R.shard_count > 1 ? (uint32_t)R.shard_index + st * (uint32_t)R.shard_count : st;
-        int tx0 = (int)(gt % (uint32_t)R.tiles_x) * R.tile_w, ty0 = (int)(gt / (uint32_t)R.tiles_x) * R.tile_h;
-        int lx = (int)(sub % sub_x) * 8 + (lane & 7), ly = (int)(sub / sub_x) * 8 + (lane >> 3);
-        int x = tx0 + lx, y = ty0 + ly;
-        bool inside = x < R.width && y < R.height;
-        size_t out_index = R.shard_count > 1 ? ((size_t)st * R.tile_h + ly) * R.tile_w + lx : (size_t)y * R.width + x;
-        F3 px = f3(0.f, 0.f, 0.f);
-        if (inside) {
-            Rng rng;
-            rng_seed(rng, (uint32_t)(y * R.width + x));                                          // hw6/src/sceneio.cpp:281-284
-            F3 color = f3(0.f, 0.f, 0.f);
-            for (int s = 0; s < R.samples; s++) {                                                // scene.cpp:111-115
-                float nx = (float)x + rng_u01(rng);
-                float ny = (float)y + rng_u01(rng);
-                float cx = R.tan_fov_x * (2 * nx / (float)R.width - 1);                          // scene.cpp:123-126 (not normalised)
-                float cy = S.tan_fov_y * (2 * ny / (float)R.height - 1);
-                F3 dir = cx * f3(S.cam_right) - cy * f3(S.cam_up) + f3(S.cam_fwd);
-                color = color + trace_tree6(S, R.ray_depth, rng, f3(S.cam_pos), dir, stack);
+        unsigned long long need = __ballot(!have_pixel);
+        if (need && !exhausted) {                                      // lanes without a pixel take the next pixel slots
+            int leader = __ffsll((long long)need) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(R.work_counter, (uint32_t)__popcll(need));
+            base = __shfl(base, leader);
+            if (base + (uint32_t)__popcll(need) >= n_slots) exhausted = true;
+            if (!have_pixel) {
+                uint32_t slot = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (slot < n_slots) {
+                    bool inside;
+                    slot_to_pixel(R, slot, x, y, inside, out_index);
+                    if (inside) {
+                        rng_seed(rng, (uint32_t)(y * R.width + x));                              // hw6/src/sceneio.cpp:281-284
+                        color = f3(0.f, 0.f, 0.f); s = 0;
+                        camera_ray();
+                        have_pixel = true;
+                    } else if (R.shard_count > 1) {                                              // padding of a border tile in the compact shard layout
+                        if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
+                        if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
+                    }
+                }
             }
-            px = R.inv_samples * color;
         }
-        if (inside || R.shard_count > 1) {
-            if (R.out_rgb) { R.out_rgb[3 * out_index] = px.x; R.out_rgb[3 * out_index + 1] = px.y; R.out_rgb[3 * out_index + 2] = px.z; }
-            if (R.out_rgb8) {
-                R.out_rgb8[3 * out_index] = inside ? tonemap1(px.x) : 0;
-                R.out_rgb8[3 * out_index + 1] = inside ? tonemap1(px.y) : 0;
-                R.out_rgb8[3 * out_index + 2] = inside ? tonemap1(px.z) : 0;
+        if (!__ballot(have_pixel)) { if (exhausted) break; else continue; }
+        if (have_pixel && machine6_step(S, R.ray_depth, rng, M, stack)) {
+            color = color + M.ret;                                                               // scene.cpp:113
+            if (++s < R.samples) camera_ray();
+            else {
+                F3 px = R.inv_samples * color;                                                   // scene.cpp:115
+                if (R.out_rgb) { R.out_rgb[3 * out_index] = px.x; R.out_rgb[3 * out_index + 1] = px.y; R.out_rgb[3 * out_index + 2] = px.z; }
+                if (R.out_rgb8) { R.out_rgb8[3 * out_index] = tonemap1(px.x); R.out_rgb8[3 * out_index + 1] = tonemap1(px.y); R.out_rgb8[3 * out_index + 2] = tonemap1(px.z); }
+                have_pixel = false;
             }
         }
     }

@@ -59,18 +59,7 @@ RT_DEV uint32_t wf_pack(int depth, bool has_saved, uint32_t sample, bool pending
     return (uint32_t)depth | (has_saved ? 16u : 0u) | (pending ? WF_PENDING_BIT : 0u) | (sample << 6);
 }
 
-RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) {
-    const int sub_x = R.tile_w >> 3, sub_per_tile = sub_x * (R.tile_h >> 3);
-    uint32_t w = slot >> 6, lane = slot & 63u;
-    uint32_t st = w / sub_per_tile, sub = w % sub_per_tile;
-    uint32_t gt = R.shard_count > 1 ? (uint32_t)R.shard_index + st * (uint32_t)R.shard_count : st;
-    int tx0 = (int)(gt % (uint32_t)R.tiles_x) * R.tile_w, ty0 = (int)(gt / (uint32_t)R.tiles_x) * R.tile_h;
-    int lx = (int)(sub % sub_x) * 8 + (int)(lane & 7), ly = (int)(sub / sub_x) * 8 + (int)(lane >> 3);
-    x = tx0 + lx; y = ty0 + ly;
-    inside = x < R.width && y < R.height;
-    out_index = R.shard_count > 1 ? ((size_t)st * R.tile_h + ly) * R.tile_w + lx : (size_t)y * R.width + x;
-}
-
+RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) { slot_to_pixel(R, slot, x, y, inside, out_index); }
 
 // ---- queue append, aggregated per workgroup -------------------------------------------------------------
 // One global atomic on a single address retires at ~88 per microsecond (MI355X_MICROARCH.md "dequeue"), which

@@ -53,6 +53,8 @@ typedef enum rt_integrator {
     RT_INTEGRATOR_HW4 = 4, /* + cosine / box-light / ellipsoid-light mixture sampling, hw4/src/scene.cpp:10-112, distributions.h */
     RT_INTEGRATOR_HW5 = 5, /* + TRIANGLE primitives, BVH over non-planes, per-pixel engines, hw5/src/scene.cpp:47-112 */
     RT_INTEGRATOR_HW6 = 6, /* triangles, DIFFUSE/METALLIC/DIELECTRIC, hw6/src/scene.cpp:47-105    */
+    RT_INTEGRATOR_HW7 = 7, /* hw8's integrator without textures: per-material BRDF without the v.n / l.n gates, alpha = roughness^2,
+                              geometric normal in the light pdf (hw7/src/scene.cpp:29-61); renders scenes created for HW8 */
     RT_INTEGRATOR_HW8 = 8  /* glTF PBR + textures + mixture sampling, hw8/src/scene.cpp:84-165     */
 } rt_integrator;
 

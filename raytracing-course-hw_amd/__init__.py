@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtamd.so")
 
 RT_INTEGRATOR_HW1, RT_INTEGRATOR_HW2, RT_INTEGRATOR_HW3, RT_INTEGRATOR_HW4, RT_INTEGRATOR_HW5 = 1, 2, 3, 4, 5
-RT_INTEGRATOR_HW6, RT_INTEGRATOR_HW8 = 6, 8
+RT_INTEGRATOR_HW6, RT_INTEGRATOR_HW7, RT_INTEGRATOR_HW8 = 6, 7, 8
 RT_FLAG_OUT_DEVICE, RT_FLAG_COUNTERS = 1, 2
 RT_OK = 0
 RT_ERR_NO_DEVICE = -2

@@ -1,7 +1,7 @@
 // CLI with the reference's surfaces:
 //   hw6-hw8 (hw8/src/main.cpp:7-18, hw8/run.sh):  rtamd_main <scene.gltf> <width> <height> <samples> <out.ppm> [<envmap.png>]
 //   hw1-hw5 (hw1/src/main.cpp:7-14, hw1/run.sh):  rtamd_main <scene.txt> <out.ppm>
-// Which snapshot's integrator replays the scene: RTAMD_SNAPSHOT=hw8 (default for glTF) | hw6, and for .txt scenes
+// Which snapshot's integrator replays the scene: RTAMD_SNAPSHOT=hw8 (default for glTF) | hw7 | hw6, and for .txt scenes
 // hw1 | hw2 | hw3 (default) | hw4 | hw5 (grammar and integrator of that snapshot).
 // The host only parses, prepares and writes the PPM; the render loop runs on the GPU through the C-ABI.
 #include "../../../include/rtamd.h"
@@ -32,11 +32,12 @@ int main(int argc, const char *argv[]) {
         out_path = argv[2];
     } else if (argc >= 6) {
         int flavor = (snap && strcmp(snap, "hw6") == 0) ? RT_INTEGRATOR_HW6 : RT_INTEGRATOR_HW8;
+        const bool hw7 = snap && strcmp(snap, "hw7") == 0; // hw7 = the hw8 scene representation rendered with hw7's material model
         if (rt_load_gltf(argv[1], flavor, &hs) != RT_OK) return die();
         p.width = (int32_t)strtol(argv[2], nullptr, 10);
         p.height = (int32_t)strtol(argv[3], nullptr, 10);
         p.samples = (int32_t)strtol(argv[4], nullptr, 10);
-        p.integrator = flavor;
+        p.integrator = hw7 ? RT_INTEGRATOR_HW7 : flavor;
         out_path = argv[5];
         if (argc > 6 && rt_host_scene_set_environment(hs, argv[6]) != RT_OK) return die();
     } else {

@@ -258,7 +258,7 @@ RT_DEV HitRec closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, Count
 // a sequential sum inside a leaf; float addition is not associative, so the same tree of additions
 // is replayed with an explicit frame stack: TODO(child) frames and ADD(partial) frames (tag bit in
 // `addmask`).  Misses contribute +0, which is the additive identity here (no term is -0).
-RT_DEV float light_pdf_one(const LightRec *L, F3 x, F3 d, bool &last) {
+RT_DEV float light_pdf_one(const LightRec *L, F3 x, F3 d, bool &last, bool geometric_normal = false) {
     TriIsect T = load_isect(&L->isect);
     last = T.pad != 0;
     float t, u, v; bool inside;
@@ -272,6 +272,7 @@ RT_DEV float light_pdf_one(const LightRec *L, F3 x, F3 d, bool &last) {
     F3 sn = n3 + u * dn1 + v * dn2;           // primitives.cpp:110
     sn = normalize(sn);                        // :117
     if (inside) sn = neg(sn);                  // :118-119
+    if (geometric_normal) { F3 n = f3(T.nx, T.ny, T.nz); sn = normalize(inside ? neg(n) : n); } // hw7: yn of the intersection
     F3 y = x + t * d;                          // distributions.h:144
     return point_prob * len2(x - y) / fabsf(dot(d, sn)); // :68-70 (pdfOne, shading normal in hw8)
 }
@@ -294,7 +295,7 @@ RT_DEV float light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack, Coun
                     for (;;) {
                         bool last;
                         if (COUNT) cnt.tris++;
-                        result += light_pdf_one(S.lights + i, x, d, last);
+                        result += light_pdf_one(S.lights + i, x, d, last, S.hw7 != 0);
                         if (last) break;
                         i++;
                     }
@@ -396,6 +397,21 @@ RT_DEV F3 material_brdf(F3 base_color, float base_metallic, F3 l, F3 v, F3 n, F3
     if (metallic < 1) {
         F3 diffuse = f3(0.f, 0.f, 0.f);
         if (dot(l, n) >= 0) diffuse = (float)(1. / RT_PI) * (base_color * color);
+        F3 ft = fresnel_term(f3(0.04f, 0.04f, 0.04f), f3(1.f, 1.f, 1.f), v, h);
+        dielectric = diffuse * (f3(1.f, 1.f, 1.f) - ft) + specular * ft;
+    }
+    return (1.0f - metallic) * dielectric + metallic * metal;
+}
+
+// hw7/src/include/material.h:44-61: per-material colour and metallic only, and none of hw8's v.n / l.n gates
+RT_DEV F3 material_brdf_hw7(F3 base_color, float base_metallic, F3 l, F3 v, F3 n, float alpha2) {
+    F3 h = normalize(l + v);
+    float specular = specular_brdf(l, v, n, alpha2);
+    F3 metal = f3(0.f, 0.f, 0.f), dielectric = f3(0.f, 0.f, 0.f);
+    float metallic = base_metallic;
+    if (metallic > 0) metal = specular * fresnel_term(base_color, f3(1.f, 1.f, 1.f), v, h);
+    if (metallic < 1) {
+        F3 diffuse = (float)(1. / RT_PI) * base_color;
         F3 ft = fresnel_term(f3(0.04f, 0.04f, 0.04f), f3(1.f, 1.f, 1.f), v, h);
         dielectric = diffuse * (f3(1.f, 1.f, 1.f) - ft) + specular * ft;
     }

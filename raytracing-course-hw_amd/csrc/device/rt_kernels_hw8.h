@@ -44,6 +44,12 @@ RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh,
     base_color = f3(m0.x, m0.y, m0.z); base_metallic = m0.w;
     int tex_color = (int)__float_as_uint(m2.x), tex_emis = (int)__float_as_uint(m2.y);
     int tex_mr = (int)__float_as_uint(m2.z), tex_nrm = (int)__float_as_uint(m2.w);
+    if (S.hw7) { // hw7/src/scene.cpp:29-61: factors only
+        sh.color = f3(1.f, 1.f, 1.f); sh.emission = f3(m1.x, m1.y, m1.z); sh.sn = sn;
+        sh.alpha = m1.w * m1.w;                                                      // pow(roughnessFactor, 2.0), :44
+        sh.metallic = 1.f;
+        return;
+    }
     sh.color = f3(1.f, 1.f, 1.f);
     if (tex_color >= 0) sh.color = sample_texture(S, tex_color, tu, tv, true);      // scene.cpp:107-115
     sh.emission = f3(m1.x, m1.y, m1.z);
@@ -104,7 +110,8 @@ RT_DEV F3 trace_path(const SceneView &S, int ray_depth, Rng &rng, F3 o, F3 d, ui
         if (comp == 0) nd = cosine_sample(rng, sh.sn);
         else if (comp == 2) nd = light_sample(S, rng, xo);
         else nd = vndf_sample(rng, sh.sn, d, sh.alpha);
-        F3 brdf = material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha); // scene.cpp:153
+        F3 brdf = S.hw7 ? material_brdf_hw7(base_color, base_metallic, nd, neg(d), sh.sn, sh.alpha * sh.alpha)
+                        : material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha); // scene.cpp:153
         // brdf < eps with eps = 1e-4L: for a float this is  brdf <= (float)1e-4  (no float lies in between)
         const float epsf = 9.99999974737875163555e-05f;
         if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) { tail = sh.emission; break; }               // :154-156

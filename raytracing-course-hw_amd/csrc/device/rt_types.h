@@ -81,6 +81,10 @@ struct SceneView {
     // the throughput of the deepest level is in [0, inf] or NaN, and that level returns exactly its emission
     // (emission + mult*0, or emission via the clamp) — the wavefront path then skips its BRDF/pdf work.
     uint32_t last_level_emission_only;
+    // 1 = replay the hw7 snapshot on this scene (set per render): no textures / normal map / environment, alpha =
+    // roughness^2 without the 0.08 floor, the ungated BRDF of hw7/src/include/material.h:44-61, and the GEOMETRIC normal in
+    // the light pdf (hw7/src/include/distributions.h:140-145).
+    uint32_t hw7;
     int32_t env_image;             // image slot of the environment map or -1
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float bg[3];

@@ -379,7 +379,7 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 for (;;) {
                     bool last;
                     if (COUNT) n_tris++;
-                    result += light_pdf_one(S.lights + i, o, d, last);
+                    result += light_pdf_one(S.lights + i, o, d, last, S.hw7 != 0);
                     if (last) break;
                     i++;
                 }
@@ -478,7 +478,8 @@ RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView 
     if (comp == 0) nd = cosine_sample(rng, sh.sn);
     else if (comp == 2) nd = light_sample(S, rng, xo);
     else nd = vndf_sample(rng, sh.sn, d, sh.alpha);
-    F3 brdf = material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha);
+    F3 brdf = S.hw7 ? material_brdf_hw7(base_color, base_metallic, nd, neg(d), sh.sn, sh.alpha * sh.alpha)
+                    : material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha);
     const float epsf = 9.99999974737875163555e-05f;
     if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) {             // scene.cpp:154-156
         wf_finish_path(S, R, W, slot, depth, sh.emission, accum, rng, sample, next);

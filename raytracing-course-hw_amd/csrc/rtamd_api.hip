@@ -350,15 +350,15 @@ size_t rt_output_elems(const rt_render_params *p) {
 
 // Rounds a pixel needs per camera sample: one per bounce; without the deepest-level shortcut the last bounce's pdf / clamp
 // step takes one more.
-static size_t wavefront_rounds(const rt_scene *scene, const RenderView &R) {
-    return (size_t)R.samples * ((size_t)R.ray_depth + (scene->view.last_level_emission_only ? 0u : 1u));
+static size_t wavefront_rounds(const SceneView &V, const RenderView &R) {
+    return (size_t)R.samples * ((size_t)R.ray_depth + (V.last_level_emission_only ? 0u : 1u));
 }
 
 // Wavefront driver: per round one traverse launch and one shade launch (device/rt_wavefront.h).
 // No host synchronisation inside: queue lengths live in device memory, one counter block per round.
-static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
+static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     const size_t n_slots = (size_t)n_work * 64;
-    const size_t rounds = wavefront_rounds(scene, R);
+    const size_t rounds = wavefront_rounds(V, R);
     if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_rounds < rounds) {
         scene->free_wf();
         auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); scene->wf_allocs.push_back(p); return p; };
@@ -386,14 +386,14 @@ static void launch_wavefront(rt_scene *scene, const RenderView &R, uint32_t n_wo
     uint32_t shade_blocks = (uint32_t)((n_slots + 255) / 256);
     if (shade_blocks > (uint32_t)scene->n_cus * 16u) shade_blocks = (uint32_t)scene->n_cus * 16u;
     unsigned long long *ctrs = count ? scene->d_counters : nullptr;
-    hipLaunchKernelGGL(dev::wf_init_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream, scene->view, R, W);
+    hipLaunchKernelGGL(dev::wf_init_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream, V, R, W);
     if (time_trace) while (scene->ev_pool.size() < 2 * rounds) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r], stream));
-        if (count) hipLaunchKernelGGL(dev::wf_traverse_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
-        else hipLaunchKernelGGL(dev::wf_traverse_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, scene->view, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
+        if (count) hipLaunchKernelGGL(dev::wf_traverse_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
+        else hipLaunchKernelGGL(dev::wf_traverse_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r + 1], stream));
-        hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, scene->view, R, W, r, ctrs);
+        hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, V, R, W, r, ctrs);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -402,11 +402,12 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
     if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW6 && p->integrator != RT_INTEGRATOR_HW3 && p->integrator != RT_INTEGRATOR_HW1 &&
-        p->integrator != RT_INTEGRATOR_HW2 && p->integrator != RT_INTEGRATOR_HW4 && p->integrator != RT_INTEGRATOR_HW5)
+        p->integrator != RT_INTEGRATOR_HW2 && p->integrator != RT_INTEGRATOR_HW4 && p->integrator != RT_INTEGRATOR_HW5 && p->integrator != RT_INTEGRATOR_HW7)
         return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown integrator");
     const bool txt_scene = scene->flavor == RT_INTEGRATOR_HW3;
     const bool txt_integrator = p->integrator >= RT_INTEGRATOR_HW1 && p->integrator <= RT_INTEGRATOR_HW5;
-    if (txt_scene != txt_integrator || (!txt_scene && p->integrator != scene->flavor))
+    const bool hw7 = p->integrator == RT_INTEGRATOR_HW7; // renders a scene prepared for hw8 with hw7's material model (no textures)
+    if (txt_scene != txt_integrator || (!txt_scene && p->integrator != scene->flavor && !(hw7 && scene->flavor == RT_INTEGRATOR_HW8)))
         return fail(RT_ERR_INVALID_ARG, "rt_render: this scene was prepared for integrator " + std::to_string(scene->flavor) +
                                             " (hw6 scenes carry no vertex normals, hw8 scenes do)");
     RenderView R{};
@@ -458,12 +459,14 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         const bool float_tan = p->integrator == RT_INTEGRATOR_HW1 || p->integrator == RT_INTEGRATOR_HW2;
         const float txt_tan_fov_y = (float_tan ? scene->viewt.tan_fov_x_f : scene->viewt.tan_fov_x) * R.height / R.width; // hw3/src/scene.cpp:101
         if (scene->flavor == RT_INTEGRATOR_HW6 && R.ray_depth > RT6_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw6 ray_depth above 8");
+        SceneView V8 = scene->view; // per-render copy: the hw7 replay switches are render parameters, not scene state
+        if (hw7) { V8.hw7 = 1; V8.last_level_emission_only = 0; V8.env_image = -1; }
         uint32_t launches = 0;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
             if (use_wavefront) {
-                launch_wavefront(scene, R, n_work, stream, count, stats != nullptr);
-                launches = 1 + 2 * (uint32_t)wavefront_rounds(scene, R);
+                launch_wavefront(scene, V8, R, n_work, stream, count, stats != nullptr);
+                launches = 1 + 2 * (uint32_t)wavefront_rounds(V8, R);
             } else if (p->integrator == RT_INTEGRATOR_HW1) {
                 uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
                 hipLaunchKernelGGL(dev::render_hw1_kernel, dim3((npx + 255) / 256), dim3(256), 0, stream, scene->viewt, R.width, R.height, txt_tan_fov_y, d_rgb, d_rgb8);
@@ -490,8 +493,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
             } else {
-                if (count) hipLaunchKernelGGL(dev::render_hw8_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
-                else hipLaunchKernelGGL(dev::render_hw8_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view, R, n_work);
+                if (count) hipLaunchKernelGGL(dev::render_hw8_kernel<true>, dim3(blocks), dim3(64), 0, stream, V8, R, n_work);
+                else hipLaunchKernelGGL(dev::render_hw8_kernel<false>, dim3(blocks), dim3(64), 0, stream, V8, R, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
             }
@@ -503,7 +506,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 128, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
-            size_t rounds = wavefront_rounds(scene, R);
+            size_t rounds = wavefront_rounds(V8, R);
             std::vector<uint32_t> ctr((rounds + 2) * 4);
             HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
             for (size_t r = 0; r < rounds; r++) { h_cnt[0] += ctr[4 * r]; if (scene->info.n_lights) h_cnt[1] += ctr[4 * r + 1]; }
@@ -522,7 +525,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
             if (use_wavefront && blocks) {
-                size_t rounds = wavefront_rounds(scene, R);
+                size_t rounds = wavefront_rounds(V8, R);
                 double sum = 0;
                 for (size_t r = 0; r < rounds; r++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * r], scene->ev_pool[2 * r + 1])); sum += e; }
                 stats->dominant_kernel_ms = sum; stats->dominant_kernel_launches = (uint32_t)rounds;

@@ -115,7 +115,7 @@ def main():
         dom_ms.append(st.dominant_kernel_ms)
         dom_launches.append(st.dominant_kernel_launches)
         if world > 1:  # the one exchange step: tonemapped tiles to rank 0 over RCCL/xGMI, assembled into the frame there
-            rtd.gather_frame(dist, out_rgb8, W, H, SPP, rank, world, 32)
+            rtd.gather_frame(dist, out_rgb8, W, H, SPP, rank, world, 32, as_numpy=False)  # the frame stays on rank 0's GPU
         return st
 
     for _ in range(args.warmup):

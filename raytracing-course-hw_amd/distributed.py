@@ -20,9 +20,11 @@ def shard_elems(width, height, samples, world, tile=32):
     return [int(rt.lib.rt_output_elems(shard_params(width, height, samples, r, world, tile))) for r in range(world)]
 
 
-def gather_frame(dist, local, width, height, samples, rank, world, tile=32):
-    """local: 1-D torch tensor holding this rank's shard buffer (u8 or f32).  Returns the full (H, W, 3) numpy
-    frame on rank 0 and None elsewhere."""
+def gather_frame(dist, local, width, height, samples, rank, world, tile=32, as_numpy=True):
+    """local: 1-D torch tensor holding this rank's shard buffer (u8 or f32).  Rank 0 gathers the buffers and assembles the
+    (H, W, 3) frame WHERE THE BUFFERS ARE (on its GPU with RCCL, on the host with gloo): shard r holds the tiles r, r+world,
+    ... in order, so each buffer is one strided assignment into the frame's tile grid.  Returns the frame on rank 0 (numpy
+    if as_numpy, else a torch tensor on the gather's device — no device-to-host copy) and None elsewhere."""
     import torch
     sizes = shard_elems(width, height, samples, world, tile)
     pad = max(sizes)
@@ -32,12 +34,13 @@ def gather_frame(dist, local, width, height, samples, rank, world, tile=32):
     if local.numel() != pad:
         send = torch.zeros(pad, dtype=local.dtype, device=local.device)
         send[:local.numel()] = local
-    bufs = [torch.zeros(pad, dtype=local.dtype, device=local.device) for _ in range(world)] if rank == 0 else None
+    bufs = [torch.empty(pad, dtype=local.dtype, device=local.device) for _ in range(world)] if rank == 0 else None
     dist.gather(send, bufs, dst=0)
     if rank != 0:
         return None
-    frame = np.zeros((height, width, 3), dtype=np.uint8 if local.dtype == torch.uint8 else np.float32)
+    tiles_x, tiles_y = (width + tile - 1) // tile, (height + tile - 1) // tile
+    grid = torch.zeros((tiles_y * tiles_x, tile, tile, 3), dtype=local.dtype, device=local.device)
     for r in range(world):
-        part = rt.unshard(shard_params(width, height, samples, r, world, tile), bufs[r][:sizes[r]].cpu().numpy())
-        frame += part  # shards are disjoint; untouched pixels of a part are zero
-    return frame
+        grid[r::world] = bufs[r][:sizes[r]].view(-1, tile, tile, 3)
+    frame = grid.view(tiles_y, tiles_x, tile, tile, 3).permute(0, 2, 1, 3, 4).reshape(tiles_y * tile, tiles_x * tile, 3)[:height, :width]
+    return frame.cpu().numpy() if as_numpy else frame

@@ -206,3 +206,33 @@ def test_reference_sphere_scenes_with_environment_map(rt, tmp_path, name):
     assert ref.mean() > 0.02
     assert rmse < RMSE_TOL and bad <= 6
     scene.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_scenes_match_oracle(rt, seed):
+    """Random triangle soups with random material factors, random small textures of all four kinds on some materials,
+    zero to three emissive materials (zero = no light component in the mixture), an environment map on odd seeds, random
+    ray depth / sample count: a sweep over combinations no hand-made scene covers."""
+    rng = np.random.default_rng(1000 + seed)
+    sd = pin_cases.random_triangle_scene(n=int(rng.integers(40, 900)), seed=100 + seed, n_emissive_mats=int(rng.integers(0, 4)))
+    images, tsrc = [], []
+    for m in sd.materials[:6]:
+        for field in ("base_color_texture", "emissive_texture", "metallic_roughness_texture", "normal_texture"):
+            if rng.uniform() < 0.35:
+                w, h = int(rng.integers(2, 33)), int(rng.integers(2, 33))
+                img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+                if field == "normal_texture":
+                    img = np.clip(img // 4 + np.array([96, 96, 180]), 0, 255).astype(np.uint8)  # mostly "up" normals
+                images.append(img)
+                tsrc.append(len(images) - 1)
+                setattr(m, field, len(tsrc) - 1)
+    env = rng.integers(0, 256, (16, 32, 3)).astype(np.uint8) if seed % 2 else None
+    sd2 = rt.SceneData(sd.positions, sd.texcoords, sd.normals, sd.tangents, sd.material_index, list(sd.materials)[:sd.n_materials],
+                       tsrc, images, sd.camera, (0.05, 0.07, 0.1), env)
+    depth, spp = int(rng.integers(2, 7)), int(rng.integers(2, 6))
+    scene = rt.Scene(sd2)
+    rgb, rgb8, _ = scene.render(56, 40, spp, ray_depth=depth)
+    ref, ref8, _ = oracle_lib.Hw8Oracle(sd2).render(56, 40, spp, ray_depth=depth)
+    rmse, bad = _report(f"random scene {seed}: {sd2.positions.shape[0]} tris, {len(images)} textures, env {env is not None}, depth {depth}, spp {spp}", rgb, ref, rgb8, ref8)
+    assert np.isfinite(ref).all() and rmse < RMSE_TOL and bad <= 4
+    scene.close()

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <limits>
 #include <stdexcept>
+#include <thread>
 
 namespace rtamd {
 namespace {
@@ -48,7 +49,9 @@ public:
     std::vector<RefNode> nodes;
     uint32_t depth = 0;
 
-    void run(uint32_t n) { nodes.clear(); depth = 0; build(0, n, 1); }
+    // The two subtrees of a node work on disjoint ranges of every array, so the large ones near the root are built on
+    // separate threads into their own node lists and spliced in afterwards in the reference's (preorder) numbering.
+    void run(uint32_t n) { nodes.clear(); depth = 0; depth = build(0, n, 1, nodes, 0); }
 
 private:
     struct KI { float k; uint32_t i; };
@@ -84,31 +87,49 @@ private:
             if (sc[i] < ans.first) ans = {sc[i], (uint32_t)(first + i)};
         return ans;
     }
-    uint32_t build(uint32_t first, uint32_t last, uint32_t d) { // bvh.h:67-109
-        if (d > depth) depth = d;
+    // Builds the subtree over [first,last) into `out` (indices relative to `out`); returns its depth.
+    uint32_t build(uint32_t first, uint32_t last, uint32_t d, std::vector<RefNode> &out, int fork_level) { // bvh.h:67-109
+        uint32_t deepest = d;
         RefNode cur;
         cur.first = first; cur.last = last;
         if (first < last) {
             cur.box = boxes_[order_[first]];
             for (uint32_t i = first + 1; i < last; i++) grow(cur.box, boxes_[order_[i]]);
         } else memset(&cur.box, 0, sizeof cur.box);
-        uint32_t pos = (uint32_t)nodes.size();
-        nodes.push_back(cur);
-        if (last - first <= 1) return pos;
+        uint32_t pos = (uint32_t)out.size();
+        out.push_back(cur);
+        if (last - first <= 1) return deepest;
         sort_axis(first, last, 0); auto sx = best_split(first, last);
         sort_axis(first, last, 1); auto sy = best_split(first, last);
         sort_axis(first, last, 2); auto sz = best_split(first, last);
         float best = smin(sx.first, smin(sy.first, sz.first));
-        if (best >= surface(cur.box) * (last - first)) return pos; // leaf with >1 triangles, z-sorted
+        if (best >= surface(cur.box) * (last - first)) return deepest; // leaf with >1 triangles, z-sorted
         uint32_t mid;
         if (best == sx.first) { mid = sx.second; sort_axis(first, last, 0); }
         else if (best == sy.first) { mid = sy.second; sort_axis(first, last, 1); }
         else { mid = sz.second; sort_axis(first, last, 2); }
-        uint32_t l = build(first, mid, d + 1);
-        nodes[pos].left = l;
-        uint32_t r = build(mid, last, d + 1);
-        nodes[pos].right = r;
-        return pos;
+        if (fork_level < 3 && last - first > 16384) { // right subtree on another thread, spliced behind the left one
+            std::vector<RefNode> right_nodes;
+            uint32_t right_depth = 0;
+            std::thread worker([&] { right_depth = build(mid, last, d + 1, right_nodes, fork_level + 1); });
+            out[pos].left = (uint32_t)out.size();
+            uint32_t left_depth = build(first, mid, d + 1, out, fork_level + 1);
+            worker.join();
+            uint32_t shift = (uint32_t)out.size();
+            out[pos].right = shift;
+            for (RefNode n : right_nodes) {
+                if (n.left != 0) { n.left += shift; n.right += shift; }
+                out.push_back(n);
+            }
+            return left_depth > right_depth ? left_depth : right_depth;
+        }
+        uint32_t l = (uint32_t)out.size();
+        out[pos].left = l;
+        uint32_t dl = build(first, mid, d + 1, out, fork_level + 1);
+        uint32_t r = (uint32_t)out.size();
+        out[pos].right = r;
+        uint32_t dr = build(mid, last, d + 1, out, fork_level + 1);
+        return dl > dr ? dl : dr;
     }
 };
 

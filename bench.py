@@ -207,8 +207,20 @@ def main():
             t1 = time.perf_counter()
             ref_rgb, _, _ = orc.render(W, H, cspp, rect=rect, threads=cores)
             dt = time.perf_counter() - t1
+            # the same code on ONE thread (BASELINE.md section 3 asks for both): a 64x36 block, a few spp, ~3 s
+            sw, sh_ = min(W, 64), min(H, 36)
+            srect = ((W - sw) // 2, (H - sh_) // 2, sw, sh_)
+            t1 = time.perf_counter()
+            orc.render(W, H, 1, rect=srect, threads=1)
+            probe1 = time.perf_counter() - t1
+            sspp = max(1, min(SPP, int(3.0 / max(probe1, 1e-3))))
+            t1 = time.perf_counter()
+            orc.render(W, H, sspp, rect=srect, threads=1)
+            dt1 = time.perf_counter() - t1
             cpu = {"value": round(cw * ch * cspp / dt / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                   "sample": f"oracle (CPU restatement, OpenMP dynamic,8) on the centre {cw}x{ch} pixel block of the same {W}x{H} frame at {cspp} spp, {dt:.1f} s"}
+                   "sample": f"oracle (CPU restatement, OpenMP dynamic,8) on the centre {cw}x{ch} pixel block of the same {W}x{H} frame at {cspp} spp, {dt:.1f} s",
+                   "value_1_thread": round(sw * sh_ * sspp / dt1 / 1e6, 5),
+                   "sample_1_thread": f"centre {sw}x{sh_} block at {sspp} spp, {dt1:.1f} s"}
         headline = args.workload.endswith("1920x1080x256") and args.spp <= 0
         result = {"metric": "Msamples/sec at 1920x1080x256spp" if headline else f"Msamples/sec ({args.workload}, spp={SPP}; NOT the headline config)",
                   "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -202,6 +202,12 @@ int rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);
  * parity-critical: reference hw8/src/include/distributions.h:103-115. */
 int rt_scene_get_light_order(const rt_scene *scene, uint32_t *out, uint32_t capacity);
 
+/* Host-only part of rt_scene_create (no GPU needed): the figure order after the reference's BVH build and the light order,
+ * as indices into the LOAD-order arrays, for the integrator family the desc belongs to (`integrator` = HW8 / HW6 for glTF
+ * scenes, HW5 for .txt scenes).  Either output may be NULL; capacities in elements.  Returns the number of lights. */
+int rt_host_prepare_orders(const rt_scene_desc *desc, int integrator, uint32_t *figure_order, uint32_t figure_capacity,
+                           uint32_t *light_order, uint32_t light_capacity);
+
 /* ---- host-side front-end (replaces sceneio::loadScene / loadTexture) -------------------- */
 typedef struct rt_host_scene rt_host_scene; /* owns the arrays a desc points into */
 

@@ -92,7 +92,7 @@ class rt_scene_info(C.Structure):
 ABI_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_output_elems", "rt_render",
                "rt_unshard", "rt_scene_get_info", "rt_scene_get_light_order", "rt_load_gltf", "rt_load_txt",
                "rt_host_scene_set_environment", "rt_host_scene_desc", "rt_host_scene_free", "rt_write_ppm",
-               "rt_decode_png", "rt_free"]
+               "rt_decode_png", "rt_free", "rt_host_prepare_orders"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -108,6 +108,7 @@ lib.rt_render.argtypes = [C.c_void_p, C.POINTER(rt_render_params), C.c_void_p, C
 lib.rt_unshard.argtypes = [C.POINTER(rt_render_params), C.c_void_p, C.c_size_t, C.c_void_p]
 lib.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(rt_scene_info)]
 lib.rt_scene_get_light_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+lib.rt_host_prepare_orders.argtypes = [C.POINTER(rt_scene_desc), C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
 lib.rt_load_gltf.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
 lib.rt_load_txt.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)] + [C.POINTER(C.c_int32)] * 4
 lib.rt_host_scene_set_environment.argtypes = [C.c_void_p, C.c_char_p]
@@ -234,6 +235,15 @@ def load_txt(path, flavor=RT_INTEGRATOR_HW3):
         return SceneData.from_desc(lib.rt_host_scene_desc(hs).contents), w.value, h.value, s.value, d.value
     finally:
         lib.rt_host_scene_free(hs)
+
+
+def host_prepare_orders(data, integrator):
+    """(figure order, light order) of the host-side scene preparation, without a GPU."""
+    n = max(1, data.positions.shape[0], len(data.primitives or ()))
+    fo, lo = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    k = _check(lib.rt_host_prepare_orders(C.byref(data.desc), integrator, fo.ctypes.data, n, lo.ctypes.data, n))
+    nf = data.positions.shape[0] if data.positions.shape[0] else len(data.primitives or ())
+    return fo[:nf], lo[:k]
 
 
 def decode_png(path):

@@ -316,6 +316,24 @@ int rt_scene_get_light_order(const rt_scene *scene, uint32_t *out, uint32_t capa
     return (int)scene->light_order.size();
 }
 
+int rt_host_prepare_orders(const rt_scene_desc *desc, int integrator, uint32_t *figure_order, uint32_t figure_capacity,
+                           uint32_t *light_order, uint32_t light_capacity) {
+    if (!desc || desc->struct_size != sizeof(rt_scene_desc)) return fail(RT_ERR_INVALID_ARG, "rt_host_prepare_orders: bad desc");
+    try {
+        std::vector<uint32_t> fo, lo;
+        if (integrator == RT_INTEGRATOR_HW8 || integrator == RT_INTEGRATOR_HW7) { PreparedScene P; prepare_scene(*desc, P); fo = P.figure_order; lo = P.light_order; }
+        else if (integrator == RT_INTEGRATOR_HW6) { PreparedScene6 P; prepare_scene_hw6(*desc, P); fo = P.figure_order; lo = P.light_order; }
+        else if (integrator == RT_INTEGRATOR_HW5) { PreparedScene5 P; prepare_scene_hw5(*desc, P); fo = P.figure_order; lo = P.light_order; }
+        else return fail(RT_ERR_UNSUPPORTED, "rt_host_prepare_orders: integrator must be HW5, HW6, HW7 or HW8");
+        if ((figure_order && figure_capacity < fo.size()) || (light_order && light_capacity < lo.size())) return fail(RT_ERR_INVALID_ARG, "rt_host_prepare_orders: buffer too small");
+        if (figure_order) memcpy(figure_order, fo.data(), fo.size() * sizeof(uint32_t));
+        if (light_order) memcpy(light_order, lo.data(), lo.size() * sizeof(uint32_t));
+        return (int)lo.size();
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARG, std::string("rt_host_prepare_orders: ") + e.what());
+    }
+}
+
 static bool resolve_tiles(const rt_render_params *p, RenderView &R, std::string &err) {
     if (p->width <= 0 || p->height <= 0 || p->samples <= 0) { err = "width, height and samples must be positive"; return false; }
     if ((int64_t)p->width * p->height >= 2147483647LL) { err = "image too large for the per-pixel seed (y*W+x must stay below 2^31-1)"; return false; }

@@ -147,3 +147,24 @@ def test_jpeg_textures_decode_close_to_libjpeg(rt, tmp_path):
     Image.fromarray(img).save(str(tmp_path / "prog.jpg"), "JPEG", progressive=True)
     with pytest.raises(rt.RtError):
         rt.decode_png(str(tmp_path / "prog.jpg"))
+
+
+def test_host_preparation_reproduces_reference_figure_and_light_orders(rt, sphere_scene):
+    """The parity-critical host logic (std::sort / std::partition replay of the reference's BVH build and light list, hw8
+    and hw5 flavours, including the threaded subtree build) checked without a GPU against the oracle, whose orders are pinned
+    against the compiled reference (tests/test_oracle_pins.py)."""
+    import oracle_lib
+    import pin_cases
+    for sd in (sphere_scene, pin_cases.random_triangle_scene(n=700, seed=11), pin_cases.random_triangle_scene(n=40000, seed=12, n_emissive_mats=3)):
+        fo, lo = rt.host_prepare_orders(sd, rt.RT_INTEGRATOR_HW8)
+        orc = oracle_lib.Hw8Oracle(sd)
+        assert np.array_equal(fo, orc.figure_order()) and np.array_equal(lo, orc.light_order())
+    for name, (mk, _, _, _) in pin_cases.HW6_CASES.items():
+        sd6 = mk()
+        fo, lo = rt.host_prepare_orders(sd6, rt.RT_INTEGRATOR_HW6)
+        orc6 = oracle_lib.Hw6Oracle(sd6)
+        assert np.array_equal(fo, orc6.figure_order()) and np.array_equal(lo, orc6.light_order()), name
+    sd5, *_ = rt.load_txt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "txt", "hw5_mixed_figures.txt"), rt.RT_INTEGRATOR_HW5)
+    fo, lo = rt.host_prepare_orders(sd5, rt.RT_INTEGRATOR_HW5)
+    ofo, olo = oracle_lib.Hw5Oracle(sd5).orders()
+    assert np.array_equal(fo, ofo) and np.array_equal(lo, olo) and len(lo) == 8

@@ -221,6 +221,34 @@ def main():
                    "sample": f"oracle (CPU restatement, OpenMP dynamic,8) on the centre {cw}x{ch} pixel block of the same {W}x{H} frame at {cspp} spp, {dt:.1f} s",
                    "value_1_thread": round(sw * sh_ * sspp / dt1 / 1e6, 5),
                    "sample_1_thread": f"centre {sw}x{sh_} block at {sspp} spp, {dt1:.1f} s"}
+            # The reference ITSELF where it can be compiled: hw7 (hw8's integrator before textures) is built from the
+            # reference's own sources into oracle/_ref/libref_hw7.so.  It renders the same geometry / lights / camera with
+            # the textures stripped, on the same pixel block; the GPU renders that scene with RT_INTEGRATOR_HW7 and the two
+            # are compared on the block.  Skipped silently when the library is not there.
+            try:
+                if oracle_lib.ref_path("libref_hw7.so") and SPP >= 8:
+                    sd7 = rt.SceneData.from_desc(sd.desc)
+                    for i in range(sd7.n_materials):
+                        m = sd7.materials[i]
+                        m.base_color_texture = m.emissive_texture = m.metallic_roughness_texture = m.normal_texture = -1
+                    sd7._build_desc()
+                    t1 = time.perf_counter()
+                    ref7 = oracle_lib.Ref7(sd7)                      # includes the reference's own BVH build
+                    t_build7 = time.perf_counter() - t1
+                    rspp = max(1, min(SPP, cspp // 2))
+                    t1 = time.perf_counter()
+                    ref7_rgb, _, _ = ref7.render(W, H, rspp, rect=rect, threads=cores)
+                    dt7 = time.perf_counter() - t1
+                    scene7 = rt.Scene(sd7)
+                    g7, _, st7 = scene7.render(W, H, rspp, integrator=rt.RT_INTEGRATOR_HW7, want_rgb8=False)
+                    crop = g7[rect[1]:rect[1] + ch, rect[0]:rect[0] + cw]
+                    scene7.close()
+                    cpu["reference_hw7"] = {"value": round(cw * ch * rspp / dt7 / 1e6, 5), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                                            "sample": f"the reference's hw7 sources (textures stripped from the scene) on the same {cw}x{ch} block at {rspp} spp, {dt7:.1f} s; its own scene build took {t_build7:.1f} s",
+                                            "gpu_same_scene_msamples_per_s": round(W * H * rspp / st7.kernel_ms / 1e3, 3),
+                                            "rmse_gpu_vs_reference_on_block": float(np.sqrt(np.mean((crop.astype(np.float64) - ref7_rgb) ** 2)))}
+            except Exception as e:  # the reference harness is optional equipment
+                cpu["reference_hw7"] = {"skipped": repr(e)[:200]}
         headline = args.workload.endswith("1920x1080x256") and args.spp <= 0
         result = {"metric": "Msamples/sec at 1920x1080x256spp" if headline else f"Msamples/sec ({args.workload}, spp={SPP}; NOT the headline config)",
                   "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -41,3 +41,35 @@ def test_hw7_and_hw8_integrators_differ_on_the_same_scene(rt):
     b, _, _ = scene.render(40, 32, 6, integrator=rt.RT_INTEGRATOR_HW8, want_rgb8=False)
     assert not np.array_equal(a, b)
     scene.close()
+
+
+def test_headline_size_frame_against_the_reference_itself(rt, tmp_path):
+    """1920x1080x256 on the benchmark scene with its textures stripped, rendered with RT_INTEGRATOR_HW7, against the
+    reference's OWN hw7 code (oracle/_ref/libref_hw7.so, compiled from /root/reference) on six 32x32 crops: the only place
+    where the GPU meets the reference directly at the headline size.  Skipped where the reference build is absent."""
+    import sys
+    import oracle_lib
+    if oracle_lib.ref_path("libref_hw7.so") is None:
+        pytest.skip("oracle/_ref/libref_hw7.so not built")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_synth_room
+    path, _ = gen_synth_room.generate(str(tmp_path), 64, 50, 43)
+    sd = rt.load_gltf(path)
+    for i in range(sd.n_materials):
+        m = sd.materials[i]
+        m.base_color_texture = m.emissive_texture = m.metallic_roughness_texture = m.normal_texture = -1
+    sd._build_desc()
+    scene = rt.Scene(sd)
+    rgb, _, st = scene.render(1920, 1080, 256, integrator=rt.RT_INTEGRATOR_HW7, want_rgb8=False)
+    print(f"hw7 full frame: {st.kernel_ms:.0f} ms = {1920 * 1080 * 256 / st.kernel_ms / 1e3:.1f} Msamples/s")
+    ref7 = oracle_lib.Ref7(sd)
+    worst, desync = 0.0, 0
+    for (x0, y0) in ((944, 524), (64, 900), (1700, 96), (400, 300), (1300, 700), (960, 40)):
+        ref, _, _ = ref7.render(1920, 1080, 256, rect=(x0, y0, 32, 32))
+        crop = rgb[y0:y0 + 32, x0:x0 + 32]
+        rmse = float(np.sqrt(np.mean((crop.astype(np.float64) - ref) ** 2)))
+        bad = int((np.abs(crop.astype(np.float64) - ref).max(axis=2) > 1e-3).sum())
+        print(f"  crop ({x0},{y0}) vs the reference: rmse {rmse:.3e}, pixels off by > 1e-3: {bad}, bit_exact {np.array_equal(crop, ref)}")
+        worst, desync = max(worst, rmse), desync + bad
+        assert ref.mean() > 0.01 and rmse < RMSE_TOL
+    scene.close()

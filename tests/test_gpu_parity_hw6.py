@@ -50,4 +50,8 @@ def test_config3_practice6_2_1024x1024x256_crop(rt):
     ref, ref8, _ = oracle_lib.Hw6Oracle(sd).render(1024, 1024, 256, rect=(x0, y0, 16, 16))
     rmse, bad = _cmp("config3 crop", rgb[y0:y0 + 16, x0:x0 + 16], ref, rgb8[y0:y0 + 16, x0:x0 + 16], ref8)
     assert rmse < RMSE_TOL
+    if oracle_lib.ref_path("libref_hw6.so"):  # the reference's own hw6 code on the same crop (65,536 camera samples)
+        rref, rref8, _ = oracle_lib.Ref6(sd).render(1024, 1024, 256, rect=(x0, y0, 16, 16))
+        rmse, bad = _cmp("config3 crop vs the reference itself", rgb[y0:y0 + 16, x0:x0 + 16], rref, rgb8[y0:y0 + 16, x0:x0 + 16], rref8)
+        assert rmse < RMSE_TOL
     scene.close()

@@ -136,6 +136,46 @@ RT_DEV float light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
     return v;
 }
 
+// The same sum through the properly keyed tree.  With no, one or two lights hit the result does not depend on the order of
+// the additions (x + 0 = x, a + b = b + a), so it is returned directly; with three or more the reference-order walk decides.
+RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
+    RayInv ray = make_ray_inv(x, d);
+    int sp = 0, k = 0;
+    float t1 = 0.f, t2 = 0.f;
+    uint32_t cur = 0;
+    for (;;) {
+        if (!(cur & RT_LEAF_BIT)) {
+            const float4 *q = reinterpret_cast<const float4 *>(S.fast_light_nodes + cur);
+            float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+            float n0, n1;
+            bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
+            bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+            uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+            if (h0 & h1) { stack[sp++] = c1; cur = c0; continue; }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else if (cur != RT_EMPTY_LEAF) {
+            uint32_t i = cur & ~RT_LEAF_BIT;
+            for (;;) {
+                Tri6Regs T = load_tri6(S.fast_lights + i);
+                float t; bool inside;
+                if (tri6_test(T, x, d, t, inside)) {
+                    F3 yn = normalize(inside ? neg(T.n) : T.n);            // primitives.cpp:31
+                    F3 y = x + t * d;
+                    float term = T.point_prob * len2(x - y) / fabsf(dot(d, yn)); // distributions.h:116-118
+                    if (k == 0) t1 = term; else t2 = term;
+                    if (++k > 2) return light_pdf_sum6(S, x, d, stack);
+                }
+                if (T.last) break;
+                i++;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return k == 2 ? t1 + t2 : t1;
+}
+
 enum { F6_MUL = 0, F6_DIEL_REFLECT = 1, F6_DIEL_REFRACT = 2 };
 struct Frame6 {
     F3 emission, mult;    // F6_MUL: result = emission + mult * child ; DIEL frames: mult = material colour
@@ -190,7 +230,7 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
                 if (dot(nd, norma) < 0) { ret = emission; evaluating = false; continue; }       // scene.cpp:64-66
                 float pdf = 0.f;
                 pdf += smax(0.f, dot(nd, norma) / RT_PI_F);                                     // distributions.h:55-58
-                if (S.n_components == 2) pdf += light_pdf_sum6(S, xo, nd, stack) / (float)S.n_lights;
+                if (S.n_components == 2) pdf += light_pdf_sum6_fast(S, xo, nd, stack) / (float)S.n_lights;
                 pdf = pdf / (float)S.n_components;
                 float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)dot(nd, norma));       // scene.cpp:69
                 f.kind = F6_MUL; f.emission = emission; f.mult = k * color;

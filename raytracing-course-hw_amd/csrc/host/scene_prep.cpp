@@ -408,6 +408,20 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out) {
     out.lights.resize(n_lights);
     for (uint32_t i = 0; i < n_lights; i++) { out.lights[i] = make(out.light_order[i]); out.lights[i].ref_index = i; }
     for (uint32_t i : light_leaf_last) out.lights[i].last = 1;
+    // The reference's light tree (constant sort key) is degenerate — thousands of box tests per query — and only the ORDER
+    // of its additions matters, which is irrelevant when at most two lights are hit.  A second, properly keyed tree over the
+    // same lights serves those queries; three or more hits fall back to the reference-order walk.
+    {
+        std::vector<uint32_t> forder = out.light_order;
+        RefBuilder fast(keys, boxes, forder);
+        fast.run(n_lights);
+        out.fast_light_bvh_depth = fast.depth;
+        std::vector<uint32_t> fast_leaf_last;
+        encode_tree(fast.nodes, out.fast_light_nodes, fast_leaf_last);
+        out.fast_lights.resize(n_lights);
+        for (uint32_t i = 0; i < n_lights; i++) out.fast_lights[i] = make(forder[i]);
+        for (uint32_t i : fast_leaf_last) out.fast_lights[i].last = 1;
+    }
     out.materials.resize(d.n_materials);
     for (uint32_t i = 0; i < d.n_materials; i++) {
         const rt_material &m = d.materials[i];

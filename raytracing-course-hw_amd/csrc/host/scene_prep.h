@@ -28,8 +28,9 @@ void prepare_scene(const rt_scene_desc &desc, PreparedScene &out);
 
 // hw6 flavour (flat-shaded triangles, hw6/src/scene.cpp): own scene tree + reference-topology light tree.
 struct PreparedScene6 {
-    std::vector<GpuNode> nodes, light_nodes;
-    std::vector<Tri6> tris, lights;
+    std::vector<GpuNode> nodes, light_nodes, fast_light_nodes;
+    std::vector<Tri6> tris, lights, fast_lights;
+    uint32_t fast_light_bvh_depth = 0;
     std::vector<GpuMaterial6> materials;
     std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index
     uint32_t bvh_depth = 0, light_bvh_depth = 0, ref_bvh_depth = 0;

@@ -199,7 +199,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             PreparedScene6 P6;
             prepare_scene_hw6(*desc, P6);
             double t1 = now_ms();
-            if (P6.bvh_depth > RT6_STACK_SIZE - 2 || P6.light_bvh_depth > RT6_STACK_SIZE - 2)
+            if (P6.bvh_depth > RT6_STACK_SIZE - 2 || P6.light_bvh_depth > RT6_STACK_SIZE - 2 || P6.fast_light_bvh_depth > RT6_STACK_SIZE - 2)
                 return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P6.bvh_depth) + "/" +
                                               std::to_string(P6.light_bvh_depth) + ")");
             uint64_t bytes = 0;
@@ -209,6 +209,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             V.tris = keep(upload(P6.tris, bytes));
             V.light_nodes = keep(upload(P6.light_nodes, bytes));
             V.lights = keep(upload(P6.lights, bytes));
+            V.fast_light_nodes = keep(upload(P6.fast_light_nodes, bytes));
+            V.fast_lights = keep(upload(P6.fast_lights, bytes));
             V.materials = keep(upload(P6.materials, bytes));
             V.n_tris = desc->n_triangles;
             V.n_lights = (uint32_t)P6.lights.size();

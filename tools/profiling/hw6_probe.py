@@ -1,0 +1,8 @@
+import sys, importlib
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+rt = importlib.import_module("raytracing-course-hw_amd")
+import pin_cases
+sd = pin_cases.load_hw6("practice6_2")
+scene = rt.Scene(sd)
+rgb, _, st = scene.render(512, 512, 32, integrator=rt.RT_INTEGRATOR_HW6, want_rgb8=False)
+print("hw6 512x512x32:", st.kernel_ms, "ms", 512*512*32/st.kernel_ms/1e3, "Msamples/s")

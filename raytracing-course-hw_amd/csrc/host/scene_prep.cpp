@@ -419,7 +419,11 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out) {
         std::vector<uint32_t> fast_leaf_last;
         encode_tree(fast.nodes, out.fast_light_nodes, fast_leaf_last);
         out.fast_lights.resize(n_lights);
-        for (uint32_t i = 0; i < n_lights; i++) out.fast_lights[i] = make(forder[i]);
+        std::vector<uint32_t> light_pos(n, 0);
+        for (uint32_t i = 0; i < n_lights; i++) light_pos[out.light_order[i]] = i;
+        for (uint32_t i = 0; i < n_lights; i++) { out.fast_lights[i] = make(forder[i]); out.fast_lights[i].ref_index = light_pos[forder[i]]; }
+        for (const RefNode &rn : light_builder.nodes) { out.light_ref.push_back(rn.left); out.light_ref.push_back(rn.right); out.light_ref.push_back(rn.first); out.light_ref.push_back(rn.last); }
+        if (out.light_ref.empty()) out.light_ref.assign(4, 0);
         for (uint32_t i : fast_leaf_last) out.fast_lights[i].last = 1;
     }
     out.materials.resize(d.n_materials);

@@ -31,6 +31,7 @@ struct PreparedScene6 {
     std::vector<GpuNode> nodes, light_nodes, fast_light_nodes;
     std::vector<Tri6> tris, lights, fast_lights;
     uint32_t fast_light_bvh_depth = 0;
+    std::vector<uint32_t> light_ref; // 4 words per reference light-tree node: left, right, first, last
     std::vector<GpuMaterial6> materials;
     std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index
     uint32_t bvh_depth = 0, light_bvh_depth = 0, ref_bvh_depth = 0;

@@ -211,6 +211,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             V.lights = keep(upload(P6.lights, bytes));
             V.fast_light_nodes = keep(upload(P6.fast_light_nodes, bytes));
             V.fast_lights = keep(upload(P6.fast_lights, bytes));
+            V.light_ref = keep(upload(P6.light_ref, bytes));
             V.materials = keep(upload(P6.materials, bytes));
             V.n_tris = desc->n_triangles;
             V.n_lights = (uint32_t)P6.lights.size();

@@ -45,6 +45,7 @@ struct WfView {
     uint32_t *q_light;
     uint32_t *ctr;          // per round r: ctr[4r+0] = trace count, +1 = light count, +2 = trace head, +3 = light head
     uint32_t n_slots;
+    uint32_t *ovf;          // SPILL variant only: WF_OVF stack entries per persistent thread beyond the WF_STACK entries in LDS
 };
 
 RT_DEV float4 *wf_rec(const WfView &W, uint32_t slot) { return W.r0 + (size_t)slot * W.stride; }
@@ -53,6 +54,7 @@ RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0
 #define WF_MISS 0xFFFFFFFFu
 #define WF_INSIDE_BIT 0x40000000u
 #define WF_STACK 32            // LDS traversal stack entries per lane
+#define WF_OVF 96              // deeper entries of the SPILL kernel variant (trees deeper than WF_STACK) live in global memory
 
 #define WF_PENDING_BIT 32u
 RT_DEV uint32_t wf_pack(int depth, bool has_saved, uint32_t sample, bool pending = false) {
@@ -224,10 +226,24 @@ RT_DEV bool wf_take(WfSlice &s, bool want, uint32_t &item) {
     return got;
 }
 
-template <bool COUNT>
+// Stack access.  The regular kernels index the LDS stack directly; the SPILL variant (selected on the host for trees deeper
+// than WF_STACK) pays a bounds check per access and keeps the deep entries in a per-thread global area.
+template <bool SPILL>
+RT_DEV void wf_spush(uint32_t (*stack)[64], uint32_t *ovf, int lds_limit, int lane, int &sp, uint32_t v) {
+    if (!SPILL || sp < lds_limit) stack[sp][lane] = v; else ovf[sp - lds_limit] = v;
+    sp++;
+}
+template <bool SPILL>
+RT_DEV uint32_t wf_spop(uint32_t (*stack)[64], const uint32_t *ovf, int lds_limit, int lane, int &sp) {
+    --sp;
+    return (!SPILL || sp < lds_limit) ? stack[sp][lane] : ovf[sp - lds_limit];
+}
+
+template <bool COUNT, bool SPILL>
 RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)[64], const uint32_t *queue, WfSlice slice,
-                          unsigned long long *counters, int refill, int leaf_batch) {
+                          unsigned long long *counters, int refill, int leaf_batch, int lds_limit) {
     const int lane = threadIdx.x & 63;
+    uint32_t *ovf = SPILL ? W.ovf + ((size_t)blockIdx.x * 256u + threadIdx.x) * WF_OVF : nullptr;
     bool active = false;
     uint32_t slot = 0, cur = 0, hit = WF_MISS;
     int sp = 0;
@@ -270,14 +286,14 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) {
                     bool swap = n1 < n0;
-                    stack[sp++][lane] = swap ? c0 : c1;
+                    wf_spush<SPILL>(stack, ovf, lds_limit, lane, sp, swap ? c0 : c1);
                     cur = swap ? c1 : c0;
                 } else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) { // traversal finished: publish the hit
                     wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
                     active = false;
-                } else cur = stack[--sp][lane];
+                } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
             }
         }
         // phase 2: every lane waiting at a leaf tests its triangles
@@ -300,7 +316,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
             if (sp == 0) {
                 wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
                 active = false;
-            } else cur = stack[--sp][lane];
+            } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
         }
     }
     if (COUNT && counters) {
@@ -312,10 +328,11 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
 
 // All-hits light sum (FiguresMix::getTotalPdf, distributions.h:148-165) with the reference's addition tree.
 // The finished sum goes straight into the pending bounce's pdf: E0.w += sum / n_lights (distributions.h:123,273).
-template <bool COUNT>
+template <bool COUNT, bool SPILL>
 RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)[64], const uint32_t *queue, WfSlice slice,
-                          unsigned long long *counters, int refill, int leaf_batch) {
+                          unsigned long long *counters, int refill, int leaf_batch, int lds_limit) {
     const int lane = threadIdx.x & 63;
+    uint32_t *ovf = SPILL ? W.ovf + ((size_t)blockIdx.x * 256u + threadIdx.x) * WF_OVF : nullptr;
     bool active = false, descending = true;
     uint32_t slot = 0, cur = 0;
     int sp = 0;
@@ -354,7 +371,7 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                     bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
                     bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
                     uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-                    if (h0 & h1) { addmask &= ~(1ull << sp); stack[sp++][lane] = c1; cur = c0; }
+                    if (h0 & h1) { addmask &= ~(1ull << sp); wf_spush<SPILL>(stack, ovf, lds_limit, lane, sp, c1); cur = c0; }
                     else if (h0) cur = c0;
                     else if (h1) cur = c1;
                     else { v = 0.f; descending = false; }
@@ -364,10 +381,9 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                     *pdf = *pdf + v / (float)S.n_lights;
                     active = false;
                 } else {
-                    --sp;
-                    uint32_t f = stack[sp][lane];
+                    uint32_t f = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
                     if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;       // left total + right total
-                    else { addmask |= 1ull << sp; stack[sp++][lane] = __float_as_uint(v); cur = f; descending = true; }
+                    else { addmask |= 1ull << sp; wf_spush<SPILL>(stack, ovf, lds_limit, lane, sp, __float_as_uint(v)); cur = f; descending = true; }
                 }
             }
         }
@@ -395,9 +411,9 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
 // Blocks [0, nb_t) own the trace queue, the rest own the light queue; nb_t follows the queue lengths weighted by the
 // measured cost of one query of each kind (a light query costs ~7/5 of a closest-hit query on the benchmark scene).
 // After its own queue a block helps with the other one's dynamic tail, so a wrong split only costs a few chunks.
-template <bool COUNT>
+template <bool COUNT, bool SPILL>
 __global__ __launch_bounds__(256) void wf_traverse_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters,
-                                                          int t_refill, int t_batch, int l_refill, int l_batch, int dyn) {
+                                                          int t_refill, int t_batch, int l_refill, int l_batch, int dyn, int lds_limit) {
     __shared__ uint32_t lds_stack[4][WF_STACK][64];
     uint32_t(*stack)[64] = lds_stack[threadIdx.x >> 6];
     const uint32_t ct = W.ctr[4 * round + 0], cl = S.n_lights ? W.ctr[4 * round + 1] : 0u;
@@ -414,9 +430,9 @@ __global__ __launch_bounds__(256) void wf_traverse_kernel(SceneView S, WfView W,
     const uint32_t *q_t = W.q_trace[round & 1], *q_l = W.q_light;
     uint32_t *head_t = W.ctr + 4 * round + 2, *head_l = W.ctr + 4 * round + 3;
     const bool tracer = blockIdx.x < nb_t;
-    if (tracer) wf_trace_loop<COUNT>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, true), counters, t_refill, t_batch);
-    if (cl) wf_light_loop<COUNT>(S, W, stack, q_l, wf_slice(cl, head_l, dyn, nb_t, nb - nb_t, !tracer), counters, l_refill, l_batch);
-    if (!tracer) wf_trace_loop<COUNT>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, false), counters, t_refill, t_batch);
+    if (tracer) wf_trace_loop<COUNT, SPILL>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, true), counters, t_refill, t_batch, lds_limit);
+    if (cl) wf_light_loop<COUNT, SPILL>(S, W, stack, q_l, wf_slice(cl, head_l, dyn, nb_t, nb - nb_t, !tracer), counters, l_refill, l_batch, lds_limit);
+    if (!tracer) wf_trace_loop<COUNT, SPILL>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, false), counters, t_refill, t_batch, lds_limit);
 }
 
 // ---- shade: finish the pending bounce (scene.cpp:158-164), then scene.cpp:89-156 for the new hit ------------------------

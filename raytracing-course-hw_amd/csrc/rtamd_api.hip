@@ -90,6 +90,7 @@ struct rt_scene {
     void free_wf() {
         for (void *p : wf_allocs) (void)hipFree(p);
         wf_allocs.clear();
+        wf = dev::WfView{};
         wf_slots = wf_levels = wf_rounds = 0;
     }
     ~rt_scene() {
@@ -390,12 +391,24 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
         scene->wf.ctr = (uint32_t *)alloc((rounds + 2) * 16);
         scene->wf_slots = n_slots; scene->wf_levels = (size_t)R.ray_depth; scene->wf_rounds = rounds;
     }
+    // Trees deeper than the LDS stacks use the SPILL kernel variant (bounds-checked stack with a global overflow area).
+    // RTAMD_WF_LDS_STACK=n (testing): pretend the LDS stacks hold only n entries, which forces the SPILL variant and its overflow area.
+    int lds_limit = WF_STACK;
+    if (const char *e = getenv("RTAMD_WF_LDS_STACK")) { int v = atoi(e); if (v >= 1 && v < WF_STACK) lds_limit = v; }
+    const bool spill = scene->info.bvh_depth > (uint32_t)lds_limit || scene->info.light_bvh_depth > (uint32_t)lds_limit;
+    if (spill && !scene->wf.ovf) {
+        void *p = nullptr;
+        HIP_CHECK(hipMalloc(&p, (size_t)scene->n_cus * 8u * 256u * WF_OVF * 4u)); // up to 8 persistent blocks per CU
+        scene->wf_allocs.push_back(p);
+        scene->wf.ovf = (uint32_t *)p;
+    }
     dev::WfView W = scene->wf;
     W.n_slots = (uint32_t)n_slots;
     W.stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
     HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * 16, stream));
     uint32_t blocks_per_cu = 4u;                                      // measured best (5 fit: 5 x 32 KB LDS per CU)
     if (const char *e = getenv("RTAMD_WF_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : blocks_per_cu;
+    if (blocks_per_cu > 8u) blocks_per_cu = 8u;
     const uint32_t persistent_blocks = (uint32_t)scene->n_cus * blocks_per_cu;
     int dyn256 = 64;                                                   // share of each queue (of 256) handed out dynamically at the tail
     if (const char *e = getenv("RTAMD_WF_DYNAMIC_256")) dyn256 = atoi(e) < 0 ? 0 : (atoi(e) > 255 ? 255 : atoi(e));
@@ -411,8 +424,14 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     if (time_trace) while (scene->ev_pool.size() < 2 * rounds) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r], stream));
-        if (count) hipLaunchKernelGGL(dev::wf_traverse_kernel<true>, dim3(persistent_blocks), dim3(256), 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
-        else hipLaunchKernelGGL(dev::wf_traverse_kernel<false>, dim3(persistent_blocks), dim3(256), 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256);
+        const dim3 pb(persistent_blocks), tb(256);
+        if (spill) {
+            if (count) hipLaunchKernelGGL((dev::wf_traverse_kernel<true, true>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+            else hipLaunchKernelGGL((dev::wf_traverse_kernel<false, true>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+        } else {
+            if (count) hipLaunchKernelGGL((dev::wf_traverse_kernel<true, false>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+            else hipLaunchKernelGGL((dev::wf_traverse_kernel<false, false>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+        }
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r + 1], stream));
         hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, V, R, W, r, ctrs);
     }
@@ -467,7 +486,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         // also the fallback when a BVH is deeper than the wavefront kernels' LDS stacks).
         const char *ksel = getenv("RTAMD_KERNEL");
         bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
-        if (scene->info.bvh_depth > WF_STACK || scene->info.light_bvh_depth > WF_STACK || scene->info.n_triangles >= 0x40000000u) use_wavefront = false;
+        if (scene->info.bvh_depth > WF_STACK + WF_OVF || scene->info.light_bvh_depth > 64 || scene->info.n_triangles >= 0x40000000u) use_wavefront = false; // light depth: 64-bit frame mask
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
         if (txt_scene && scene->txt_has_triangles && p->integrator != RT_INTEGRATOR_HW5) return fail(RT_ERR_INVALID_ARG, "rt_render: a .txt scene with TRIANGLE figures renders with RT_INTEGRATOR_HW5 only");

@@ -123,3 +123,21 @@ def test_bad_parameters_are_rejected(rt, sphere_scene):
         with pytest.raises(rt.RtError):
             scene.render(kw.pop("width"), kw.pop("height"), kw.pop("samples"), **kw)
     scene.close()
+
+
+def test_spill_variant_of_the_traversal_kernel(rt, sphere_scene, monkeypatch):
+    """Trees deeper than the 32-entry LDS stacks run a bounds-checked kernel variant whose deep stack entries live in a
+    global overflow area.  RTAMD_WF_LDS_STACK=3 pretends the LDS stacks hold three entries, so ordinary scenes exercise the
+    overflow path on nearly every ray; pixels must not change."""
+    import pin_cases
+    for sd, (w, h, spp) in ((sphere_scene, (64, 48, 5)), (pin_cases.random_triangle_scene(n=700, seed=21), (72, 48, 5))):
+        scene = rt.Scene(sd)
+        assert scene.info().bvh_depth > 3
+        ref, ref8, st0 = scene.render(w, h, spp)
+        monkeypatch.setenv("RTAMD_WF_LDS_STACK", "3")
+        rgb, rgb8, st = scene.render(w, h, spp)
+        monkeypatch.delenv("RTAMD_WF_LDS_STACK")
+        assert st.launches == st0.launches > 1 and np.array_equal(rgb, ref) and np.array_equal(rgb8, ref8)
+        orc, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
+        assert np.array_equal(rgb, orc)
+        scene.close()

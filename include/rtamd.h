@@ -133,7 +133,8 @@ typedef struct rt_scene_desc {
     uint32_t n_images;
     const rt_image *images;
     const rt_image *environment_map; /* NULL = none (hw8/src/scene.cpp:90-97) */
-    uint32_t n_primitives;           /* analytic primitives (HW1/HW3) */
+    uint32_t n_primitives;           /* analytic primitives (HW1-HW5); a scene with neither triangles nor primitives is a .txt
+                                        scene when camera.fov_y == 0 && camera.fov_x != 0, else a glTF scene */
     const rt_primitive *primitives;
     rt_camera camera;
     float bg_color[3];

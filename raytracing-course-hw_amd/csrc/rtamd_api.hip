@@ -122,7 +122,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         double t0 = now_ms();
         // Analytic primitives only: a .txt scene (hw1 / hw3).
-        if (desc->n_triangles == 0 && desc->n_primitives > 0) {
+        // (A scene without any figure counts as a .txt scene when its camera carries only CAMERA_FOV_X, as the .txt loader leaves it.)
+        if (desc->n_triangles == 0 && (desc->n_primitives > 0 || (desc->camera.fov_x != 0.f && desc->camera.fov_y == 0.f))) {
             std::vector<GpuPrim> prims(desc->n_primitives);
             for (uint32_t i = 0; i < desc->n_primitives; i++) {
                 const rt_primitive &p = desc->primitives[i];

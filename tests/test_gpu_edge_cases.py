@@ -141,3 +141,25 @@ def test_spill_variant_of_the_traversal_kernel(rt, sphere_scene, monkeypatch):
         orc, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
         assert np.array_equal(rgb, orc)
         scene.close()
+
+
+def test_empty_scenes_render_the_background(rt, tmp_path):
+    """No figures at all: every integrator returns the background colour for every sample (hw8/src/scene.cpp:90-92,
+    hw3/src/scene.cpp:36-38, hw1/src/scene.cpp:8)."""
+    cam = rt.rt_camera()
+    cam.position, cam.right, cam.up, cam.forward = (0, 0, 2), (1, 0, 0), (0, 1, 0), (0, 0, -1)
+    cam.fov_y, cam.fov_x = 0.9, 1.1
+    z = np.zeros((0, 9), np.float32)
+    sd = rt.SceneData(z, np.zeros((0, 6), np.float32), z, np.zeros((0, 12), np.float32), np.zeros(0, np.uint32), [], camera=cam, bg=(0.25, 0.5, 0.75))
+    scene = rt.Scene(sd)
+    rgb, rgb8, _ = scene.render(40, 24, 3)
+    assert np.allclose(rgb, np.array([0.25, 0.5, 0.75], np.float32), rtol=0, atol=1e-6) and rgb8.std(axis=(0, 1)).max() == 0
+    scene.close()
+    txt = tmp_path / "empty.txt"
+    txt.write_text("DIMENSIONS 24 16\nBG_COLOR 0.2 0.4 0.6\nCAMERA_POSITION 0 0 0\nCAMERA_RIGHT 1 0 0\nCAMERA_UP 0 1 0\nCAMERA_FORWARD 0 0 -1\nCAMERA_FOV_X 1.0\nRAY_DEPTH 4\nSAMPLES 2\n")
+    for flavor in (rt.RT_INTEGRATOR_HW1, rt.RT_INTEGRATOR_HW2, rt.RT_INTEGRATOR_HW3, rt.RT_INTEGRATOR_HW4, rt.RT_INTEGRATOR_HW5):
+        sdt, w, h, spp, depth = rt.load_txt(str(txt), flavor)
+        scene = rt.Scene(sdt)
+        rgb, _, _ = scene.render(w, h, max(1, spp), integrator=flavor, ray_depth=depth, want_rgb8=False)
+        assert np.allclose(rgb, np.array([0.2, 0.4, 0.6], np.float32), rtol=0, atol=1e-6), flavor
+        scene.close()

@@ -119,7 +119,8 @@ def test_more_shards_than_tiles(rt, sphere_scene):
 def test_bad_parameters_are_rejected(rt, sphere_scene):
     scene = rt.Scene(sphere_scene)
     for kw in (dict(width=0, height=4, samples=1), dict(width=4, height=4, samples=0), dict(width=4, height=4, samples=1, ray_depth=17),
-               dict(width=4, height=4, samples=1, shard_index=3, shard_count=2), dict(width=4, height=4, samples=1, shard_count=2, tile=12)):
+               dict(width=4, height=4, samples=1, shard_index=3, shard_count=2), dict(width=4, height=4, samples=1, shard_count=2, tile=12),
+               dict(width=65536, height=32768, samples=1)):  # y*W+x would leave the 31-bit seed range of minstd_rand
         with pytest.raises(rt.RtError):
             scene.render(kw.pop("width"), kw.pop("height"), kw.pop("samples"), **kw)
     scene.close()

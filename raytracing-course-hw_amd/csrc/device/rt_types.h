@@ -72,6 +72,7 @@ struct SceneView {
     const TriShade *tri_shade;
     const GpuNode *light_nodes;    // light BVH in the reference's topology, root = 0
     const LightRec *lights;
+    const uint16_t *light_sep;     // range-minimum table of the separation depths of neighbouring lights (scene_prep.h)
     const GpuMaterial *materials;
     const GpuImage *images;
     const uint8_t *texels;

@@ -43,7 +43,8 @@ struct WfView {
     uint32_t stride;
     uint32_t *q_trace[2];
     uint32_t *q_light;
-    uint32_t *ctr;          // per round r: ctr[4r+0] = trace count, +1 = light count, +2 = trace head, +3 = light head
+    uint32_t *ctr;          // per round r, WF_CTR words: +0 trace count, +1 light count, +2 trace head, +3 light head, +4 slow-light count
+    uint32_t *q_slow;       // light queries of this round that the lean loop hands to wf_light_exact_kernel
     uint32_t n_slots;
     uint32_t *ovf;          // SPILL variant only: WF_OVF stack entries per persistent thread beyond the WF_STACK entries in LDS
 };
@@ -53,6 +54,7 @@ RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0
 
 #define WF_MISS 0xFFFFFFFFu
 #define WF_INSIDE_BIT 0x40000000u
+#define WF_CTR 8               // counter words per round
 #define WF_STACK 32            // LDS traversal stack entries per lane
 #define WF_OVF 96              // deeper entries of the SPILL kernel variant (trees deeper than WF_STACK) live in global memory
 
@@ -407,32 +409,163 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
     if (COUNT && counters) { atomicAdd(&counters[2], n_nodes); atomicAdd(&counters[3], n_tris); }
 }
 
+// The same sum, decoupled: WHICH lights the ray hits is found by a plain all-hits walk (no frames, left child first, so the
+// hits come out in the reference's light order); in WHAT ORDER their terms are added matters only for three or more hits
+// (x + 0 = x, a + b = b + a) and is then rebuilt from the depths at which neighbouring hits separate in the reference tree
+// (SceneView::light_sep): sum(node) = sum(left) + sum(right), a side without hits is the additive identity, a leaf adds its
+// hits in index order.
+// Hits are kept in the top of the lane's LDS stack column ({index, term} pairs growing downwards); a query whose hits would
+// run into its stack, or with more than WF_MAX_LIGHT_HITS of them, is handed to wf_light_exact_kernel (frame walk of rt_device.h).
+#define WF_MAX_LIGHT_HITS 5
+template <bool COUNT>
+RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*stack)[64], const uint32_t *queue, WfSlice slice,
+                               unsigned long long *counters, int refill, int leaf_batch, uint32_t *slow_count) {
+    const int lane = threadIdx.x & 63;
+    bool active = false, overflow = false;
+    uint32_t slot = 0, cur = 0;
+    int sp = 0, k = 0;
+    F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
+    RayInv ray = make_ray_inv(o, d);
+    unsigned long long n_nodes = 0, n_tris = 0;
+    // Hit j of the finished walk: light index in stack[31-2j], term in stack[30-2j] (ascending indices); the bottom of the
+    // column is free by then and holds the separation depths while the terms are merged.
+    auto finish = [&]() {
+        active = false;
+        if (overflow) { W.q_slow[atomicAdd(slow_count, 1u)] = slot; return; }
+        float v = 0.f;
+        if (k == 1) v = __uint_as_float(stack[WF_STACK - 2][lane]);
+        else if (k == 2) v = __uint_as_float(stack[WF_STACK - 2][lane]) + __uint_as_float(stack[WF_STACK - 4][lane]);
+        else if (k > 2) {
+            // Separation depth of each pair of neighbouring hits (two independent table reads each), then merge the pair that
+            // separates DEEPEST first: the node where they separate has exactly these two groups under its left and right
+            // child, so this rebuilds sum(node) = sum(left) + sum(right) bottom-up; inside a leaf the pseudo depths make it
+            // ((a + b) + c).  Terms live in column words 30-2j, depths in words 0..k-2.
+            const uint32_t nl = S.n_lights;
+            for (int j = 1; j < k; j++) {
+                uint32_t a0 = stack[WF_STACK - 1 - 2 * (j - 1)][lane], b0 = stack[WF_STACK - 1 - 2 * j][lane]; // boundaries a0 .. b0-1
+                uint32_t len = b0 - a0;
+                uint32_t lv = 31u - (uint32_t)__clz((int)len);
+                uint16_t m0 = S.light_sep[(size_t)lv * nl + a0], m1 = S.light_sep[(size_t)lv * nl + (b0 - (1u << lv))];
+                stack[j - 1][lane] = m0 < m1 ? m0 : m1;
+            }
+            for (int n = k; n > 1; n--) {
+                int best = 1;
+                uint32_t bd = stack[0][lane];
+                for (int i = 2; i < n; i++) { uint32_t di = stack[i - 1][lane]; if (di > bd) { bd = di; best = i; } }
+                float merged = __uint_as_float(stack[WF_STACK - 2 - 2 * (best - 1)][lane]) + __uint_as_float(stack[WF_STACK - 2 - 2 * best][lane]);
+                stack[WF_STACK - 2 - 2 * (best - 1)][lane] = __float_as_uint(merged);
+                for (int i = best; i < n - 1; i++) {
+                    stack[WF_STACK - 2 - 2 * i][lane] = stack[WF_STACK - 2 - 2 * (i + 1)][lane];
+                    stack[i - 1][lane] = stack[i][lane];
+                }
+            }
+            v = __uint_as_float(stack[WF_STACK - 2][lane]);
+        }
+        int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
+        float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
+        *pdf = *pdf + v / (float)S.n_lights;                                  // distributions.h:123,273
+    };
+    for (;;) {
+        unsigned long long idle = __ballot(!active);
+        if (idle && (slice.pos < slice.end || !slice.done) && (__popcll(idle) >= refill || idle == ~0ull)) {
+            if (slice.pos >= slice.end) wf_steal(slice);
+            uint32_t item = 0;
+            if (wf_take(slice, !active, item)) {
+                slot = queue[item];
+                const float4 *r = wf_rec(W, slot);
+                float4 q0 = r[0], q1 = r[1];
+                o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
+                ray = make_ray_inv(o, d);
+                cur = 0; sp = 0; k = 0; overflow = false;
+                active = true;
+            }
+        }
+        if (!__ballot(active)) break;
+        for (;;) { // phase 1: inner nodes
+            bool inner = active && !(cur & RT_LEAF_BIT);
+            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= leaf_batch) break;
+            if (inner) {
+                const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
+                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+                if (COUNT) n_nodes++;
+                float n0, n1;
+                bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
+                bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
+                else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp == 0) finish();
+                else cur = stack[--sp][lane];
+            }
+        }
+        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    bool last;
+                    if (COUNT) n_tris++;
+                    float term = light_pdf_one(S.lights + i, o, d, last, S.hw7 != 0);
+                    if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
+                        if (k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= WF_STACK) overflow = true;
+                        else { stack[WF_STACK - 1 - 2 * k][lane] = i; stack[WF_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
+                    }
+                    if (last) break;
+                    i++;
+                }
+            }
+            if (sp == 0) finish();
+            else cur = stack[--sp][lane];
+        }
+    }
+    if (COUNT && counters) { atomicAdd(&counters[2], n_nodes); atomicAdd(&counters[3], n_tris); }
+}
+
 // ---- traverse: both loops in one persistent launch -------------------------------------------------------------------
 // Blocks [0, nb_t) own the trace queue, the rest own the light queue; nb_t follows the queue lengths weighted by the
-// measured cost of one query of each kind (a light query costs ~7/5 of a closest-hit query on the benchmark scene).
+// measured cost of one query of each kind (about equal on the benchmark scene since the light loop became frame-free).
 // After its own queue a block helps with the other one's dynamic tail, so a wrong split only costs a few chunks.
 template <bool COUNT, bool SPILL>
 __global__ __launch_bounds__(256) void wf_traverse_kernel(SceneView S, WfView W, uint32_t round, unsigned long long *counters,
                                                           int t_refill, int t_batch, int l_refill, int l_batch, int dyn, int lds_limit) {
     __shared__ uint32_t lds_stack[4][WF_STACK][64];
     uint32_t(*stack)[64] = lds_stack[threadIdx.x >> 6];
-    const uint32_t ct = W.ctr[4 * round + 0], cl = S.n_lights ? W.ctr[4 * round + 1] : 0u;
+    const uint32_t ct = W.ctr[WF_CTR * round + 0], cl = S.n_lights ? W.ctr[WF_CTR * round + 1] : 0u;
     const uint32_t nb = gridDim.x;
     uint32_t nb_t = nb;
     if (cl) {
-        unsigned long long kt = ((uint32_t)dyn >> 16) & 255u, kl = (uint32_t)dyn >> 24;  // cost weights packed by the host (0 = default 5 : 7, measured best on the benchmark scene)
-        if (!kt || !kl) { kt = 5; kl = 7; }
+        unsigned long long kt = ((uint32_t)dyn >> 16) & 255u, kl = (uint32_t)dyn >> 24;  // cost weights packed by the host (0 = default 1 : 1, measured best on the benchmark scene)
+        if (!kt || !kl) { kt = 1; kl = 1; }
         unsigned long long wt = kt * ct, wl = kl * cl;
         nb_t = (uint32_t)((wt * nb + (wt + wl) / 2) / (wt + wl));
         if (nb_t < 1u) nb_t = 1u;
         if (nb_t > nb - 1u) nb_t = nb - 1u;
     }
     const uint32_t *q_t = W.q_trace[round & 1], *q_l = W.q_light;
-    uint32_t *head_t = W.ctr + 4 * round + 2, *head_l = W.ctr + 4 * round + 3;
+    uint32_t *head_t = W.ctr + WF_CTR * round + 2, *head_l = W.ctr + WF_CTR * round + 3;
     const bool tracer = blockIdx.x < nb_t;
     if (tracer) wf_trace_loop<COUNT, SPILL>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, true), counters, t_refill, t_batch, lds_limit);
-    if (cl) wf_light_loop<COUNT, SPILL>(S, W, stack, q_l, wf_slice(cl, head_l, dyn, nb_t, nb - nb_t, !tracer), counters, l_refill, l_batch, lds_limit);
+    if (cl) {
+        if (SPILL) wf_light_loop<COUNT, true>(S, W, stack, q_l, wf_slice(cl, head_l, dyn, nb_t, nb - nb_t, !tracer), counters, l_refill, l_batch, lds_limit);
+        else wf_light_loop_lean<COUNT>(S, W, stack, q_l, wf_slice(cl, head_l, dyn, nb_t, nb - nb_t, !tracer), counters, l_refill, l_batch, W.ctr + WF_CTR * round + 4);
+    }
     if (!tracer) wf_trace_loop<COUNT, SPILL>(S, W, stack, q_t, wf_slice(ct, head_t, dyn, 0u, nb_t, false), counters, t_refill, t_batch, lds_limit);
+}
+
+// The few light queries the lean loop could not finish: the plain reference-order frame walk (light_pdf_sum), one lane each.
+__global__ __launch_bounds__(64) void wf_light_exact_kernel(SceneView S, WfView W, uint32_t round) {
+    const uint32_t count = W.ctr[WF_CTR * round + 4];
+    uint32_t stack[RT_STACK_SIZE];
+    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < count; i += gridDim.x * 64u) {
+        uint32_t slot = W.q_slow[i];
+        const float4 *r = wf_rec(W, slot);
+        float4 q0 = r[0], q1 = r[1];
+        Counters cnt; cnt.closest = cnt.lightq = cnt.nodes = cnt.tris = 0;
+        float v = light_pdf_sum<false>(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), stack, cnt);
+        int depth = (int)(__float_as_uint(r[3].w) & 15u);
+        float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
+        *pdf = *pdf + v / (float)S.n_lights;
+    }
 }
 
 // ---- shade: finish the pending bounce (scene.cpp:158-164), then scene.cpp:89-156 for the new hit ------------------------
@@ -525,8 +658,8 @@ __global__ __launch_bounds__(256, WF_SHADE_OCC) void wf_shade_kernel(SceneView S
     Pusher to_light; to_light.buf = buf_l; to_light.cnt = &cnt_l;
     Pusher next; next.buf = buf_n; next.cnt = &cnt_n;
     const uint32_t *queue = W.q_trace[round & 1];
-    const uint32_t count = W.ctr[4 * round + 0];
-    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + 4 * (round + 1) + 0, *light_count = W.ctr + 4 * (round + 1) + 1;
+    const uint32_t count = W.ctr[WF_CTR * round + 0];
+    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + WF_CTR * (round + 1) + 0, *light_count = W.ctr + WF_CTR * (round + 1) + 1;
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t i = base + threadIdx.x;
         if (i < count) wf_shade_item(S, R, W, queue[i], to_light, next, counters);

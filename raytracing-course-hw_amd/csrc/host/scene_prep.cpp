@@ -256,6 +256,39 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     light_builder.run(n_lights);
     out.light_bvh_depth = light_builder.depth;
     encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    { // separation depths of neighbouring lights + sparse table for range minima (see scene_prep.h)
+        const std::vector<RefNode> &rn = light_builder.nodes;
+        const uint32_t nl = n_lights;
+        std::vector<uint16_t> sep(nl ? nl : 1, 0);
+        if (nl > 1) {
+            std::vector<std::pair<uint32_t, uint32_t>> todo; // node, depth
+            todo.push_back({0u, 0u});
+            while (!todo.empty()) {
+                auto [node, depth] = todo.back();
+                todo.pop_back();
+                const RefNode &nd = rn[node];
+                if (nd.left == 0) { // leaf: its lights are added left to right, so the LAST boundary is the shallowest
+                    for (uint32_t b = nd.first; b + 1 < nd.last; b++) sep[b] = (uint16_t)std::min<uint32_t>(65535u, 32768u + (nd.last - 2 - b));
+                    continue;
+                }
+                sep[rn[nd.right].first - 1] = (uint16_t)depth; // boundary between the last light of the left child and the first of the right
+                todo.push_back({nd.left, depth + 1});
+                todo.push_back({nd.right, depth + 1});
+            }
+        }
+        uint32_t levels = 1;
+        while ((1u << levels) < (nl ? nl : 1)) levels++;
+        out.light_sep_levels = levels;
+        out.light_sep.assign((size_t)levels * (nl ? nl : 1), 0);
+        const size_t stride = nl ? nl : 1;
+        for (size_t b = 0; b < stride; b++) out.light_sep[b] = sep[b];
+        for (uint32_t j = 1; j < levels; j++)
+            for (size_t b = 0; b < stride; b++) {
+                size_t o2 = b + (1u << (j - 1));
+                uint16_t a = out.light_sep[(j - 1) * stride + b], c = o2 < stride ? out.light_sep[(j - 1) * stride + o2] : a;
+                out.light_sep[j * stride + b] = a < c ? a : c;
+            }
+    }
     out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
 
     // ---- 3. records ---------------------------------------------------------------------------------

@@ -10,6 +10,12 @@ namespace rtamd {
 
 struct PreparedScene {
     std::vector<GpuNode> nodes, light_nodes;
+    // Order of the light-pdf additions without walking the reference tree: light_sep[j * n_lights + i] = the shallowest
+    // separation depth among the boundaries i .. i + 2^j - 1 (boundary b lies between lights b and b+1 of the reference order;
+    // its depth is that of the reference-tree node whose children hold the two lights, or, inside one leaf, a pseudo depth
+    // that grows towards the leaf's first light).  A range minimum over it gives the depth at which two hit lights separate.
+    std::vector<uint16_t> light_sep;
+    uint32_t light_sep_levels = 0;
     std::vector<TriIsect> isect;
     std::vector<TriShade> shade;
     std::vector<LightRec> lights;

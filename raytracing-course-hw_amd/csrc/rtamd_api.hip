@@ -255,6 +255,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         V.tri_isect = keep(upload(P.isect, bytes));
         V.tri_shade = keep(upload(P.shade, bytes));
         V.light_nodes = keep(upload(P.light_nodes, bytes));
+        V.light_sep = keep(upload(P.light_sep, bytes));
         V.lights = keep(upload(P.lights, bytes));
         V.materials = keep(upload(P.materials, bytes));
         V.images = keep(upload(P.images, bytes));
@@ -389,7 +390,8 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
         scene->wf.q_trace[0] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_trace[1] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_light = (uint32_t *)alloc(n_slots * 4);
-        scene->wf.ctr = (uint32_t *)alloc((rounds + 2) * 16);
+        scene->wf.ctr = (uint32_t *)alloc((rounds + 2) * WF_CTR * 4);
+        scene->wf.q_slow = (uint32_t *)alloc(n_slots * 4);
         scene->wf_slots = n_slots; scene->wf_levels = (size_t)R.ray_depth; scene->wf_rounds = rounds;
     }
     // Trees deeper than the LDS stacks use the SPILL kernel variant (bounds-checked stack with a global overflow area).
@@ -406,7 +408,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     dev::WfView W = scene->wf;
     W.n_slots = (uint32_t)n_slots;
     W.stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
-    HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * 16, stream));
+    HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * WF_CTR * 4, stream));
     uint32_t blocks_per_cu = 4u;                                      // measured best (5 fit: 5 x 32 KB LDS per CU)
     if (const char *e = getenv("RTAMD_WF_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : blocks_per_cu;
     if (blocks_per_cu > 8u) blocks_per_cu = 8u;
@@ -434,6 +436,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
             else hipLaunchKernelGGL((dev::wf_traverse_kernel<false, false>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
         }
         if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r + 1], stream));
+        if (!spill && V.n_lights) hipLaunchKernelGGL(dev::wf_light_exact_kernel, dim3((unsigned)scene->n_cus), dim3(64), 0, stream, V, W, r);
         hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, V, R, W, r, ctrs);
     }
     HIP_CHECK(hipGetLastError());
@@ -548,14 +551,14 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
             size_t rounds = wavefront_rounds(V8, R);
-            std::vector<uint32_t> ctr((rounds + 2) * 4);
+            std::vector<uint32_t> ctr((rounds + 2) * WF_CTR);
             HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
-            for (size_t r = 0; r < rounds; r++) { h_cnt[0] += ctr[4 * r]; if (scene->info.n_lights) h_cnt[1] += ctr[4 * r + 1]; }
+            for (size_t r = 0; r < rounds; r++) { h_cnt[0] += ctr[WF_CTR * r]; if (scene->info.n_lights) { h_cnt[1] += ctr[WF_CTR * r + 1]; h_cnt[11] += ctr[WF_CTR * r + 4]; } }
             h_cnt[0] -= h_cnt[10]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
         }
         if (count && getenv("RTAMD_DEBUG_COUNTERS"))
-            fprintf(stderr, "[rtamd] trace kernel: wave node-iterations %llu, leaf phases %llu (lanes %llu), refills %llu; lane node visits %llu, tri tests %llu\n",
-                    h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7], h_cnt[8], h_cnt[9]);
+            fprintf(stderr, "[rtamd] light queries finished by the exact kernel: %llu of %llu; trace kernel: wave node-iterations %llu, leaf phases %llu (lanes %llu), refills %llu; lane node visits %llu, tri tests %llu\n",
+                    h_cnt[11], h_cnt[1], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7], h_cnt[8], h_cnt[9]);
         if (own_rgb) { (void)hipFree(d_rgb); own_rgb = false; }
         if (own_rgb8) { (void)hipFree(d_rgb8); own_rgb8 = false; }
         if (stats) {

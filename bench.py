@@ -158,7 +158,7 @@ def main():
         k_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         samples_per_render = st.samples  # this rank's share
         render_gbs = bps * samples_per_render / (k_ms * 1e-3) / 1e9
-        # Dominant kernel = wf_traverse_kernel (closest-hit + light-sum traversal in one persistent launch; ~73 % of GPU
+        # Dominant kernel = wf_traverse_kernel (closest-hit + light-sum traversal in one persistent launch; ~74 % of GPU
         # time, profiles/).  Its algorithmic bytes are the root-to-leaf parts of SURVEY 8(d): per closest-hit query
         # (ceil(log2 N_tri)+1) nodes x 32 B + 36 B positions, per light-pdf query the same with N_light.
         wavefront = st.dominant_kernel_launches > 1

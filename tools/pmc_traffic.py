@@ -23,7 +23,7 @@ def main():
     tot = {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]}
     for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if kernel + "<false>" in r["Kernel_Name"] and r["Counter_Name"] in tot:
+            if kernel + "<false" in r["Kernel_Name"] and r["Counter_Name"] in tot:
                 tot[r["Counter_Name"]][0] += 1
                 tot[r["Counter_Name"]][1] += float(r["Counter_Value"])
     if not tot["FETCH_SIZE"][0] or not tot["WRITE_SIZE"][0]:

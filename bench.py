@@ -45,8 +45,8 @@ def algorithmic_bytes_per_sample(n_tris, n_lights, s_bar, p_bar, t_bar, spp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)  # the first render also allocates the path-state buffers
     ap.add_argument("--workload", default="synth_room_v1_1920x1080x256", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (profiling only: the result is not the headline metric)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",

@@ -55,7 +55,9 @@ RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0
 #define WF_MISS 0xFFFFFFFFu
 #define WF_INSIDE_BIT 0x40000000u
 #define WF_CTR 8               // counter words per round
-#define WF_STACK 32            // LDS traversal stack entries per lane
+#ifndef WF_STACK
+#define WF_STACK 30            // LDS traversal stack entries per lane: 30 KB per block, so that five blocks are resident per CU
+#endif
 #define WF_OVF 96              // deeper entries of the SPILL kernel variant (trees deeper than WF_STACK) live in global memory
 
 #define WF_PENDING_BIT 32u

@@ -409,7 +409,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     W.n_slots = (uint32_t)n_slots;
     W.stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
     HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * WF_CTR * 4, stream));
-    uint32_t blocks_per_cu = 4u;                                      // measured best (5 fit: 5 x 32 KB LDS per CU)
+    uint32_t blocks_per_cu = 5u;                                      // 5 x 30 KB of stacks fit the 160 KB LDS (which is handed out in 1280-byte granules: 32 KB blocks fit only 4 times)
     if (const char *e = getenv("RTAMD_WF_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : blocks_per_cu;
     if (blocks_per_cu > 8u) blocks_per_cu = 8u;
     const uint32_t persistent_blocks = (uint32_t)scene->n_cus * blocks_per_cu;

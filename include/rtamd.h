@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 2
+#define RTAMD_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -159,6 +159,14 @@ typedef struct rt_render_params {
     int32_t shard_index, shard_count;
     uint32_t flags;
     void *stream;         /* hipStream_t to launch on, NULL = default stream */
+    /* 0 or 1 = replay mode: one std::minstd_rand per pixel seeded y*W+x draws all of the pixel's samples, as the reference does
+     * (hw8/src/sceneio.cpp:389-391) -- the mode every parity claim is made in.
+     * K > 1 = throughput mode (RT_INTEGRATOR_HW8 / HW7 only): K independent streams per pixel, stream k seeded
+     * y*W+x + k*W*H and drawing samples/K samples (samples must be a multiple of K, W*H*K < 2^31-1); the same estimator
+     * with decorrelated sub-streams, so a small frame or shard fills the GPU.  Deterministic, but NOT the reference's pixels:
+     * it agrees with replay mode statistically only. */
+    int32_t sample_streams;
+    int32_t reserved;     /* must be 0 */
 } rt_render_params;
 
 typedef struct rt_stats {

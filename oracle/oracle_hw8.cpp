@@ -651,6 +651,11 @@ void rto_hw8_bvh_stats(void *p, uint32_t *out4) {
     out4[2] = (uint32_t)s->lightmix.bvh.nodes.size(); out4[3] = s->lightmix.bvh.depth;
 }
 
+// Test hook for the product's throughput mode (include/rtamd.h: sample_streams): stream k of a pixel is an ordinary replay of
+// the reference loop with the engine seeded y*width + x + k*width*height.  0 = the reference's seeding.
+static uint32_t g_seed_offset = 0;
+void rto_hw8_set_seed_offset(uint32_t off) { g_seed_offset = off; }
+
 // Render the pixel rectangle [x0,x0+w) x [y0,y0+h) of a width x height image.
 // out_rgb: w*h*3 linear float radiance (nullable); out8: w*h*3 tonemapped bytes (nullable).
 // Mirrors the loop body of sceneio.cpp:387-396 (seed = y*width + x of the FULL image).
@@ -665,7 +670,7 @@ int rto_hw8_render(void *p, int width, int height, int samples, int ray_depth, i
         tl_cnt = Counters{};
         int x = x0 + j % w, y = y0 + j / w;
         int i = y * width + x;
-        rng_t rng(i);
+        rng_t rng((uint32_t)i + g_seed_offset);
         V3 px = s->get_pixel(rng, x, y);
         if (out_rgb) { out_rgb[3 * j] = px.x; out_rgb[3 * j + 1] = px.y; out_rgb[3 * j + 2] = px.z; }
         if (out8) to_extern(gamma_corrected(aces_tonemap(px)), out8 + 3 * j);

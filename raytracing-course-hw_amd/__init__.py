@@ -72,7 +72,8 @@ class rt_scene_desc(C.Structure):
 class rt_render_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32),
                 ("ray_depth", C.c_int32), ("integrator", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
-                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p)]
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p),
+                ("sample_streams", C.c_int32), ("reserved", C.c_int32)]
 
 
 class rt_stats(C.Structure):
@@ -261,13 +262,14 @@ def write_ppm(path, rgb8):
 
 
 def make_params(width, height, samples, integrator=RT_INTEGRATOR_HW8, ray_depth=0, shard_index=0, shard_count=1,
-                tile=32, flags=0, stream=None):
+                tile=32, flags=0, stream=None, sample_streams=0):
     p = rt_render_params()
     p.struct_size = C.sizeof(rt_render_params)
     p.width, p.height, p.samples, p.ray_depth, p.integrator = width, height, samples, ray_depth, integrator
     p.tile_w = p.tile_h = tile
     p.shard_index, p.shard_count, p.flags = shard_index, shard_count, flags
     p.stream = stream
+    p.sample_streams = sample_streams  # 0/1 = replay mode (reference pixels); K > 1 = throughput mode, statistical parity only
     return p
 
 

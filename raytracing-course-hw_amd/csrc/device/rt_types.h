@@ -103,6 +103,13 @@ struct RenderView {
     uint8_t *out_rgb8;             // nullable
     uint32_t *work_counter;        // dynamic tile queue head
     unsigned long long *counters;  // nullable: [closest, lightq, node_visits, tri_tests]
+    // Throughput mode (rt_render_params.sample_streams = K > 1, wavefront path only): K independent random streams per pixel,
+    // `samples` is then the count PER STREAM, path slot = stream * n_pixslots + pixel slot, every slot leaves its unnormalised
+    // sum in `partial` and wf_reduce_streams_kernel adds the K sums of a pixel in stream order.
+    int32_t streams;               // 0 or 1 = replay mode (the reference's one stream per pixel)
+    uint32_t n_pixslots;           // pixel slots of this shard (64 per 8x8 sub-tile)
+    uint32_t seed_stride;          // stream k of pixel i is seeded with i + k * seed_stride (= width * height)
+    float *partial;                // [streams][n_pixslots][3]
 };
 
 } // namespace rtamd

@@ -65,7 +65,9 @@ RT_DEV uint32_t wf_pack(int depth, bool has_saved, uint32_t sample, bool pending
     return (uint32_t)depth | (has_saved ? 16u : 0u) | (pending ? WF_PENDING_BIT : 0u) | (sample << 6);
 }
 
-RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) { slot_to_pixel(R, slot, x, y, inside, out_index); }
+RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) {
+    slot_to_pixel(R, R.streams > 1 ? slot % R.n_pixslots : slot, x, y, inside, out_index);
+}
 
 // ---- queue append, aggregated per workgroup -------------------------------------------------------------
 // One global atomic on a single address retires at ~88 per microsecond (MI355X_MICROARCH.md "dequeue"), which
@@ -128,6 +130,9 @@ RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView
         r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
         r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(0, rng.has_saved, sample)));
         wf_push(next, slot);
+    } else if (R.streams > 1) {                                      // throughput mode: this stream's unnormalised sum
+        float *o = R.partial + 3 * (size_t)slot;
+        o[0] = accum.x; o[1] = accum.y; o[2] = accum.z;
     } else {
         F3 px = R.inv_samples * accum;                               // scene.cpp:176
         if (R.out_rgb) { R.out_rgb[3 * out_index] = px.x; R.out_rgb[3 * out_index + 1] = px.y; R.out_rgb[3 * out_index + 2] = px.z; }
@@ -150,13 +155,13 @@ __global__ __launch_bounds__(256) void wf_init_kernel(SceneView S, RenderView R,
             int x, y; bool inside; size_t out_index;
             wf_slot_to_pixel(R, slot, x, y, inside, out_index);
             if (!inside) { // padding of a border tile in the compact shard layout
-                if (R.shard_count > 1) {
+                if (R.shard_count > 1 && slot < (R.streams > 1 ? R.n_pixslots : W.n_slots)) {
                     if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
                     if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
                 }
             } else {
                 Rng rng;
-                rng_seed(rng, (uint32_t)(y * R.width + x));          // sceneio.cpp:389-391
+                rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (slot / R.n_pixslots) * R.seed_stride : 0u)); // sceneio.cpp:389-391
                 F3 o, d;
                 wf_camera_ray(S, R, rng, x, y, o, d);
                 float4 *r = wf_rec(W, slot);
@@ -647,6 +652,23 @@ RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView 
     r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(depth, rng.has_saved, sample, true)));
     wf_push(next, slot);                                                   // traced speculatively next round ...
     if (S.n_lights) wf_push(to_light, slot);                               // ... beside its own light-pdf sum
+}
+
+// Throughput mode epilogue: pixel = float(1/spp) * (sum of its K stream sums, added in stream order), then the usual tonemap.
+__global__ __launch_bounds__(256) void wf_reduce_streams_kernel(RenderView R) {
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < R.n_pixslots; p += gridDim.x * 256u) {
+        int x, y; bool inside; size_t out_index;
+        slot_to_pixel(R, p, x, y, inside, out_index);
+        if (!inside) continue;
+        F3 sum = f3(0.f, 0.f, 0.f);
+        for (int k = 0; k < R.streams; k++) {
+            const float *q = R.partial + 3 * ((size_t)k * R.n_pixslots + p);
+            sum = sum + f3(q[0], q[1], q[2]);
+        }
+        F3 px = R.inv_samples * sum;
+        if (R.out_rgb) { R.out_rgb[3 * out_index] = px.x; R.out_rgb[3 * out_index + 1] = px.y; R.out_rgb[3 * out_index + 2] = px.z; }
+        if (R.out_rgb8) { R.out_rgb8[3 * out_index] = tonemap1(px.x); R.out_rgb8[3 * out_index + 1] = tonemap1(px.y); R.out_rgb8[3 * out_index + 2] = tonemap1(px.z); }
+    }
 }
 
 #ifndef WF_SHADE_OCC

@@ -86,6 +86,8 @@ struct rt_scene {
     dev::WfView wf{};
     size_t wf_slots = 0, wf_levels = 0, wf_rounds = 0;
     std::vector<void *> wf_allocs;
+    float *d_partial = nullptr;      // throughput mode: per-stream pixel sums
+    size_t partial_bytes = 0;
     std::vector<hipEvent_t> ev_pool; // brackets every launch of the dominant kernel when stats are requested
     void free_wf() {
         for (void *p : wf_allocs) (void)hipFree(p);
@@ -95,6 +97,7 @@ struct rt_scene {
     }
     ~rt_scene() {
         free_wf();
+        if (d_partial) (void)hipFree(d_partial);
         for (void *p : allocations) (void)hipFree(p);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
@@ -482,6 +485,14 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         R.tan_fov_x = scene->view.tan_fov_y * R.width / R.height;
         R.inv_samples = (float)(1.0 / R.samples);
         uint32_t n_work = R.n_shard_tiles * (uint32_t)((R.tile_w >> 3) * (R.tile_h >> 3));
+        const int streams = p->sample_streams > 1 ? p->sample_streams : 1;
+        if (p->reserved != 0) return fail(RT_ERR_INVALID_ARG, "rt_render: reserved must be 0");
+        if (streams > 1) { // throughput mode (include/rtamd.h: sample_streams)
+            if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW7) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 is implemented for RT_INTEGRATOR_HW8 / HW7 only");
+            if (streams > 256 || R.samples % streams != 0) return fail(RT_ERR_INVALID_ARG, "rt_render: samples must be a multiple of sample_streams (at most 256 streams)");
+            if ((int64_t)R.width * R.height * streams >= 2147483647LL) return fail(RT_ERR_INVALID_ARG, "rt_render: width*height*sample_streams must stay below 2^31-1 (stream seeds)");
+            if ((uint64_t)n_work * 64u * (uint64_t)streams >= 0x40000000ull) return fail(RT_ERR_LIMIT, "rt_render: too many path slots (pixels of this shard x sample_streams)");
+        }
         HIP_CHECK(hipMemsetAsync(scene->d_work_counter, 0, 4, stream));
         if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 128, stream));
         uint32_t blocks = (uint32_t)scene->n_cus * 16u;
@@ -492,6 +503,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
         if (scene->info.bvh_depth > WF_STACK + WF_OVF || scene->info.light_bvh_depth > 64 || scene->info.n_triangles >= 0x40000000u) use_wavefront = false; // light depth: 64-bit frame mask
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
+        if (streams > 1 && !use_wavefront) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 needs the wavefront kernels (RTAMD_KERNEL=mega or a tree beyond their limits is in effect)");
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
         if (txt_scene && scene->txt_has_triangles && p->integrator != RT_INTEGRATOR_HW5) return fail(RT_ERR_INVALID_ARG, "rt_render: a .txt scene with TRIANGLE figures renders with RT_INTEGRATOR_HW5 only");
         if (p->integrator == RT_INTEGRATOR_HW5 && R.ray_depth > RT4_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw5 ray_depth above 8");
@@ -509,8 +521,25 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
             if (use_wavefront) {
-                launch_wavefront(scene, V8, R, n_work, stream, count, stats != nullptr);
+                if (streams > 1) {
+                    R.streams = streams; R.n_pixslots = n_work * 64u; R.seed_stride = (uint32_t)R.width * (uint32_t)R.height;
+                    R.samples /= streams;                           // per stream; inv_samples stays 1 / (all samples of the pixel)
+                    const size_t need = (size_t)streams * R.n_pixslots * 3 * sizeof(float);
+                    if (scene->partial_bytes < need) {
+                        if (scene->d_partial) (void)hipFree(scene->d_partial);
+                        scene->d_partial = nullptr; scene->partial_bytes = 0;
+                        HIP_CHECK(hipMalloc((void **)&scene->d_partial, need));
+                        scene->partial_bytes = need;
+                    }
+                    R.partial = scene->d_partial;
+                }
+                launch_wavefront(scene, V8, R, n_work * (uint32_t)streams, stream, count, stats != nullptr);
                 launches = 1 + 2 * (uint32_t)wavefront_rounds(V8, R);
+                if (streams > 1) {
+                    hipLaunchKernelGGL(dev::wf_reduce_streams_kernel, dim3((R.n_pixslots + 255u) / 256u), dim3(256), 0, stream, R);
+                    HIP_CHECK(hipGetLastError());
+                    launches++;
+                }
             } else if (p->integrator == RT_INTEGRATOR_HW1) {
                 uint32_t npx = (uint32_t)R.width * (uint32_t)R.height;
                 hipLaunchKernelGGL(dev::render_hw1_kernel, dim3((npx + 255) / 256), dim3(256), 0, stream, scene->viewt, R.width, R.height, txt_tan_fov_y, d_rgb, d_rgb8);
@@ -582,7 +611,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 int w = R.width - tx0 < R.tile_w ? R.width - tx0 : R.tile_w, h = R.height - ty0 < R.tile_h ? R.height - ty0 : R.tile_h;
                 px += (uint64_t)w * h;
             }
-            stats->samples = px * (uint64_t)R.samples;
+            stats->samples = px * (uint64_t)R.samples * (uint64_t)streams;
             stats->closest_hit_queries = h_cnt[0]; stats->light_pdf_queries = h_cnt[1];
             stats->node_visits = h_cnt[2]; stats->triangle_tests = h_cnt[3];
         }

@@ -1,0 +1,89 @@
+"""Throughput mode (rt_render_params.sample_streams = K > 1): K decorrelated random streams per pixel.
+
+It is NOT the reference's pixel stream, so its parity with the reference is statistical; what can be checked exactly is that
+stream k of a pixel is an ordinary replay of the reference's per-pixel loop (hw8/src/sceneio.cpp:387-396, scene.cpp:167-177) with
+the engine seeded y*W+x + k*W*H — which the oracle reproduces through its seed-offset hook."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import pin_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_streams(sd, w, h, spp, k_streams, depth=0):
+    orc = oracle_lib.Hw8Oracle(sd)
+    per = spp // k_streams
+    total = np.zeros((h, w, 3), np.float32)
+    for k in range(k_streams):
+        part, _, _ = orc.render(w, h, per, ray_depth=depth, seed_offset=k * w * h)
+        total = total + part * np.float32(per)          # float(1/per) * sum -> sum (to an ulp)
+    return total * np.float32(1.0 / spp)
+
+
+@pytest.mark.parametrize("case", ["sphere", "soup"])
+def test_each_stream_is_a_replay_with_an_offset_seed(rt, sphere_scene, case):
+    sd = sphere_scene if case == "sphere" else pin_cases.random_triangle_scene(n=300, seed=5)
+    w, h, spp, k = 48, 36, 12, 4
+    scene = rt.Scene(sd)
+    rgb, rgb8, st = scene.render(w, h, spp, sample_streams=k)
+    ref = _oracle_streams(sd, w, h, spp, k)
+    err = np.abs(rgb.astype(np.float64) - ref)
+    tol = 2e-6 * np.maximum(1.0, np.abs(ref))           # the oracle's per-stream mean is multiplied back to a sum: ulp-level slack
+    print(f"{case}: K={k} max |gpu - composed oracle| {err.max():.2e}")
+    assert np.all(err <= tol)
+    assert st.samples == w * h * spp
+    # one stream is the replay mode itself
+    a, a8, _ = scene.render(w, h, spp)
+    b, b8, _ = scene.render(w, h, spp, sample_streams=1)
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a8, b8)
+    # deterministic, and different from replay mode
+    again, _, _ = scene.render(w, h, spp, sample_streams=k)
+    assert np.array_equal(again, rgb, equal_nan=True) and not np.array_equal(a, rgb, equal_nan=True)
+    scene.close()
+
+
+def test_shards_of_a_throughput_render_assemble_to_the_frame(rt, sphere_scene):
+    scene = rt.Scene(sphere_scene)
+    w, h, spp, k = 72, 40, 8, 4                          # border tiles are padded
+    full, full8, _ = scene.render(w, h, spp, sample_streams=k)
+    acc, acc8 = np.zeros_like(full), np.zeros_like(full8)
+    for r in range(3):
+        p = rt.make_params(w, h, spp, shard_index=r, shard_count=3, tile=16, sample_streams=k)
+        buf, buf8, _ = scene.render(w, h, spp, shard_index=r, shard_count=3, tile=16, sample_streams=k)
+        acc += rt.unshard(p, buf)
+        acc8 += rt.unshard(p, buf8)
+    assert np.array_equal(acc, full) and np.array_equal(acc8, full8)
+    scene.close()
+
+
+def test_statistical_agreement_with_replay_mode(rt, sphere_scene):
+    """Same estimator, different random numbers: against a 2048-spp replay render both 64-spp images have the same error level and
+    no bias (mean signed difference within 4 standard errors)."""
+    scene = rt.Scene(sphere_scene)
+    w, h = 96, 64
+    conv, _, _ = scene.render(w, h, 2048, want_rgb8=False)
+    replay, _, _ = scene.render(w, h, 64, want_rgb8=False)
+    thr, _, _ = scene.render(w, h, 64, want_rgb8=False, sample_streams=8)
+    scene.close()
+    ok = np.isfinite(conv).all(axis=2) & np.isfinite(replay).all(axis=2) & np.isfinite(thr).all(axis=2)
+    e_r, e_t = (replay - conv)[ok].astype(np.float64), (thr - conv)[ok].astype(np.float64)
+    rmse_r, rmse_t = np.sqrt((e_r ** 2).mean()), np.sqrt((e_t ** 2).mean())
+    bias_t, se_t = e_t.mean(), e_t.std() / np.sqrt(e_t.size)
+    print(f"rmse vs 2048 spp: replay {rmse_r:.4f}, throughput(K=8) {rmse_t:.4f}; bias {bias_t:.2e} (standard error {se_t:.2e})")
+    assert 0.75 < rmse_t / rmse_r < 1.33
+    assert abs(bias_t) < 4 * se_t + 1e-6
+
+
+def test_throughput_mode_rejects_what_it_cannot_do(rt, sphere_scene):
+    scene = rt.Scene(sphere_scene)
+    with pytest.raises(rt.RtError):
+        scene.render(16, 16, 10, sample_streams=4)       # 10 is not a multiple of 4
+    with pytest.raises(rt.RtError):
+        scene.render(16, 16, 1024, sample_streams=512)   # more than 256 streams
+    scene.close()
+    s6 = rt.Scene(pin_cases.hw6_soup())
+    with pytest.raises(rt.RtError):
+        s6.render(16, 16, 4, integrator=rt.RT_INTEGRATOR_HW6, sample_streams=2)
+    s6.close()

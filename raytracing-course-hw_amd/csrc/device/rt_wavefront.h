@@ -47,6 +47,7 @@ struct WfView {
     uint32_t *q_slow;       // light queries of this round that the lean loop hands to wf_light_exact_kernel
     uint32_t n_slots;
     uint32_t *ovf;          // SPILL variant only: WF_OVF stack entries per persistent thread beyond the WF_STACK entries in LDS
+    uint32_t slot_base;     // this pipeline's first path slot (the frame's slots are cut into independent pipelines, one per stream)
 };
 
 RT_DEV float4 *wf_rec(const WfView &W, uint32_t slot) { return W.r0 + (size_t)slot * W.stride; }
@@ -65,8 +66,9 @@ RT_DEV uint32_t wf_pack(int depth, bool has_saved, uint32_t sample, bool pending
     return (uint32_t)depth | (has_saved ? 16u : 0u) | (pending ? WF_PENDING_BIT : 0u) | (sample << 6);
 }
 
-RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) {
-    slot_to_pixel(R, R.streams > 1 ? slot % R.n_pixslots : slot, x, y, inside, out_index);
+// `gslot` = W.slot_base + the pipeline-local slot that indexes the path state
+RT_DEV void wf_slot_to_pixel(const RenderView &R, uint32_t gslot, int &x, int &y, bool &inside, size_t &out_index) {
+    slot_to_pixel(R, R.streams > 1 ? gslot % R.n_pixslots : gslot, x, y, inside, out_index);
 }
 
 // ---- queue append, aggregated per workgroup -------------------------------------------------------------
@@ -121,7 +123,7 @@ RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView
     accum = accum + L;
     sample++;
     int x, y; bool inside; size_t out_index;
-    wf_slot_to_pixel(R, slot, x, y, inside, out_index);
+    wf_slot_to_pixel(R, slot + W.slot_base, x, y, inside, out_index);
     if (sample < (uint32_t)R.samples) {
         F3 o, d;
         wf_camera_ray(S, R, rng, x, y, o, d);
@@ -131,7 +133,7 @@ RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView
         r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(0, rng.has_saved, sample)));
         wf_push(next, slot);
     } else if (R.streams > 1) {                                      // throughput mode: this stream's unnormalised sum
-        float *o = R.partial + 3 * (size_t)slot;
+        float *o = R.partial + 3 * (size_t)(slot + W.slot_base);
         o[0] = accum.x; o[1] = accum.y; o[2] = accum.z;
     } else {
         F3 px = R.inv_samples * accum;                               // scene.cpp:176
@@ -153,15 +155,16 @@ __global__ __launch_bounds__(256) void wf_init_kernel(SceneView S, RenderView R,
         uint32_t slot = base + threadIdx.x;
         if (slot < W.n_slots) {
             int x, y; bool inside; size_t out_index;
-            wf_slot_to_pixel(R, slot, x, y, inside, out_index);
+            const uint32_t gslot = slot + W.slot_base;
+            wf_slot_to_pixel(R, gslot, x, y, inside, out_index);
             if (!inside) { // padding of a border tile in the compact shard layout
-                if (R.shard_count > 1 && slot < (R.streams > 1 ? R.n_pixslots : W.n_slots)) {
+                if (R.shard_count > 1 && (R.streams <= 1 || gslot < R.n_pixslots)) {
                     if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
                     if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
                 }
             } else {
                 Rng rng;
-                rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (slot / R.n_pixslots) * R.seed_stride : 0u)); // sceneio.cpp:389-391
+                rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (gslot / R.n_pixslots) * R.seed_stride : 0u)); // sceneio.cpp:389-391
                 F3 o, d;
                 wf_camera_ray(S, R, rng, x, y, o, d);
                 float4 *r = wf_rec(W, slot);

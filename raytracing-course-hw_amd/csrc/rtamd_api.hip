@@ -84,7 +84,11 @@ struct rt_scene {
     int n_cus = 256;
     // wavefront path state (grown on demand, reused across renders)
     dev::WfView wf{};
-    size_t wf_slots = 0, wf_levels = 0, wf_rounds = 0;
+    size_t wf_slots = 0, wf_levels = 0, wf_ctr_words = 0, wf_ovf_words = 0;
+    int wf_pipes = 1;                // pipelines of the last wavefront render and the counter words of each
+    size_t wf_ctr_block = 0;
+    hipStream_t wf_streams[4] = {nullptr, nullptr, nullptr, nullptr}; // one per pipeline when a render uses more than one
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> wf_allocs;
     float *d_partial = nullptr;      // throughput mode: per-stream pixel sums
     size_t partial_bytes = 0;
@@ -93,7 +97,7 @@ struct rt_scene {
         for (void *p : wf_allocs) (void)hipFree(p);
         wf_allocs.clear();
         wf = dev::WfView{};
-        wf_slots = wf_levels = wf_rounds = 0;
+        wf_slots = wf_levels = wf_ctr_words = wf_ovf_words = 0;
     }
     ~rt_scene() {
         free_wf();
@@ -102,6 +106,8 @@ struct rt_scene {
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (int h = 0; h < 4; h++) { if (wf_streams[h]) (void)hipStreamDestroy(wf_streams[h]); if (ev_join[h]) (void)hipEventDestroy(ev_join[h]); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
     }
 };
 
@@ -383,35 +389,50 @@ static size_t wavefront_rounds(const SceneView &V, const RenderView &R) {
 
 // Wavefront driver: per round one traverse launch and one shade launch (device/rt_wavefront.h).
 // No host synchronisation inside: queue lengths live in device memory, one counter block per round.
+// RTAMD_WF_PIPELINES=n (experiment, default 1): cut the frame into n independent pipelines (disjoint path slots, own queues and
+// counters), each a chain traverse -> shade -> traverse ... on its own stream, so that one pipeline's kernels could fill the CUs
+// another leaves idle in the tail of a launch.  Pixels do not depend on the cut (paths never interact; tests force n = 2..4).
+// Measured on the benchmark frame: 2 pipelines 281, 3 pipelines 258 against 304 Msamples/s with one -- the halved queues lose
+// more to ramp-up and drain than the overlap returns -- so one pipeline stays the default.
+#define WF_MAX_PIPES 4
+static int wavefront_pipelines(uint32_t n_work) {
+    int p = 1;
+    if (const char *e = getenv("RTAMD_WF_PIPELINES")) { int v = atoi(e); if (v >= 1 && v <= WF_MAX_PIPES) p = v; }
+    while (p > 1 && n_work < (uint32_t)p) p--;
+    return p;
+}
+
 static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     const size_t n_slots = (size_t)n_work * 64;
     const size_t rounds = wavefront_rounds(V, R);
-    if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_rounds < rounds) {
+    const int pipes = wavefront_pipelines(n_work);
+    const size_t ctr_block = (rounds + 2) * WF_CTR; // words per pipeline
+    if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_ctr_words < ctr_block * pipes) {
         scene->free_wf();
         auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); scene->wf_allocs.push_back(p); return p; };
         scene->wf.r0 = (float4 *)alloc(n_slots * (64 + 32 * (size_t)R.ray_depth));
         scene->wf.q_trace[0] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_trace[1] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_light = (uint32_t *)alloc(n_slots * 4);
-        scene->wf.ctr = (uint32_t *)alloc((rounds + 2) * WF_CTR * 4);
+        scene->wf.ctr = (uint32_t *)alloc(ctr_block * WF_MAX_PIPES * 4);
         scene->wf.q_slow = (uint32_t *)alloc(n_slots * 4);
-        scene->wf_slots = n_slots; scene->wf_levels = (size_t)R.ray_depth; scene->wf_rounds = rounds;
+        scene->wf_slots = n_slots; scene->wf_levels = (size_t)R.ray_depth; scene->wf_ctr_words = ctr_block * WF_MAX_PIPES;
     }
+    scene->wf_pipes = pipes; scene->wf_ctr_block = ctr_block;
     // Trees deeper than the LDS stacks use the SPILL kernel variant (bounds-checked stack with a global overflow area).
     // RTAMD_WF_LDS_STACK=n (testing): pretend the LDS stacks hold only n entries, which forces the SPILL variant and its overflow area.
     int lds_limit = WF_STACK;
     if (const char *e = getenv("RTAMD_WF_LDS_STACK")) { int v = atoi(e); if (v >= 1 && v < WF_STACK) lds_limit = v; }
     const bool spill = scene->info.bvh_depth > (uint32_t)lds_limit || scene->info.light_bvh_depth > (uint32_t)lds_limit;
-    if (spill && !scene->wf.ovf) {
+    const size_t ovf_block = (size_t)scene->n_cus * 8u * 256u * WF_OVF; // words per pipeline: up to 8 persistent blocks per CU
+    if (spill && scene->wf_ovf_words < ovf_block * pipes) {
         void *p = nullptr;
-        HIP_CHECK(hipMalloc(&p, (size_t)scene->n_cus * 8u * 256u * WF_OVF * 4u)); // up to 8 persistent blocks per CU
-        scene->wf_allocs.push_back(p);
+        HIP_CHECK(hipMalloc(&p, ovf_block * pipes * 4u));
+        scene->wf_allocs.push_back(p); // a smaller earlier area stays allocated until free_wf()
         scene->wf.ovf = (uint32_t *)p;
+        scene->wf_ovf_words = ovf_block * pipes;
     }
-    dev::WfView W = scene->wf;
-    W.n_slots = (uint32_t)n_slots;
-    W.stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
-    HIP_CHECK(hipMemsetAsync(W.ctr, 0, (rounds + 2) * WF_CTR * 4, stream));
+    HIP_CHECK(hipMemsetAsync(scene->wf.ctr, 0, ctr_block * pipes * 4, stream));
     uint32_t blocks_per_cu = 5u;                                      // 5 x 30 KB of stacks fit the 160 KB LDS (which is handed out in 1280-byte granules: 32 KB blocks fit only 4 times)
     if (const char *e = getenv("RTAMD_WF_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : blocks_per_cu;
     if (blocks_per_cu > 8u) blocks_per_cu = 8u;
@@ -423,26 +444,69 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
     const int t_refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL), t_batch = env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH);
     const int l_refill = env_int("RTAMD_LIGHT_REFILL", WF_REFILL), l_batch = env_int("RTAMD_LIGHT_LEAF_BATCH", WF_LEAF_BATCH);
-    uint32_t shade_blocks = (uint32_t)((n_slots + 255) / 256);
-    if (shade_blocks > (uint32_t)scene->n_cus * 16u) shade_blocks = (uint32_t)scene->n_cus * 16u;
     unsigned long long *ctrs = count ? scene->d_counters : nullptr;
-    hipLaunchKernelGGL(dev::wf_init_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream, V, R, W);
-    if (time_trace) while (scene->ev_pool.size() < 2 * rounds) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
-    for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
-        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r], stream));
-        const dim3 pb(persistent_blocks), tb(256);
-        if (spill) {
-            if (count) hipLaunchKernelGGL((dev::wf_traverse_kernel<true, true>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
-            else hipLaunchKernelGGL((dev::wf_traverse_kernel<false, true>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
-        } else {
-            if (count) hipLaunchKernelGGL((dev::wf_traverse_kernel<true, false>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
-            else hipLaunchKernelGGL((dev::wf_traverse_kernel<false, false>), pb, tb, 0, stream, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+    if (time_trace) while (scene->ev_pool.size() < 2 * rounds * pipes) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
+
+    // the pipelines: contiguous ranges of 64-slot groups, the state arrays offset accordingly
+    dev::WfView Wp[WF_MAX_PIPES];
+    hipStream_t sp[WF_MAX_PIPES];
+    uint32_t shade_blocks[WF_MAX_PIPES];
+    if (pipes > 1 && !scene->wf_streams[0]) {
+        for (int h = 0; h < WF_MAX_PIPES; h++) {
+            HIP_CHECK(hipStreamCreateWithFlags(&scene->wf_streams[h], hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&scene->ev_join[h], hipEventDisableTiming));
         }
-        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * r + 1], stream));
-        if (!spill && V.n_lights) hipLaunchKernelGGL(dev::wf_light_exact_kernel, dim3((unsigned)scene->n_cus), dim3(64), 0, stream, V, W, r);
-        hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks), dim3(256), 0, stream, V, R, W, r, ctrs);
+        HIP_CHECK(hipEventCreateWithFlags(&scene->ev_fork, hipEventDisableTiming));
+    }
+    const uint32_t stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
+    uint32_t first = 0;
+    for (int h = 0; h < pipes; h++) {
+        const uint32_t groups = n_work / (uint32_t)pipes + ((uint32_t)h < n_work % (uint32_t)pipes ? 1u : 0u);
+        const size_t base = (size_t)first * 64;
+        dev::WfView W = scene->wf;
+        W.stride = stride;
+        W.r0 += base * stride;
+        W.q_trace[0] += base; W.q_trace[1] += base; W.q_light += base; W.q_slow += base;
+        W.ctr += (size_t)h * ctr_block;
+        if (W.ovf) W.ovf += (size_t)h * ovf_block;
+        W.n_slots = groups * 64u;
+        W.slot_base = (uint32_t)base;
+        Wp[h] = W;
+        sp[h] = pipes > 1 ? scene->wf_streams[h] : stream;
+        shade_blocks[h] = (W.n_slots + 255u) / 256u;
+        if (shade_blocks[h] > (uint32_t)scene->n_cus * 16u) shade_blocks[h] = (uint32_t)scene->n_cus * 16u;
+        first += groups;
+    }
+    if (pipes > 1) {
+        HIP_CHECK(hipEventRecord(scene->ev_fork, stream));
+        for (int h = 0; h < pipes; h++) HIP_CHECK(hipStreamWaitEvent(sp[h], scene->ev_fork, 0));
+    }
+    for (int h = 0; h < pipes; h++)
+        hipLaunchKernelGGL(dev::wf_init_kernel, dim3((Wp[h].n_slots + 255u) / 256u), dim3(256), 0, sp[h], V, R, Wp[h]);
+    const dim3 pb(persistent_blocks), tb(256);
+    for (uint32_t r = 0; r < (uint32_t)rounds; r++) {
+        for (int h = 0; h < pipes; h++) {
+            const dev::WfView &W = Wp[h];
+            hipStream_t st = sp[h];
+            if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * ((size_t)r * pipes + h)], st));
+            if (spill) {
+                if (count) hipLaunchKernelGGL((dev::wf_traverse_kernel<true, true>), pb, tb, 0, st, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+                else hipLaunchKernelGGL((dev::wf_traverse_kernel<false, true>), pb, tb, 0, st, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+            } else {
+                if (count) hipLaunchKernelGGL((dev::wf_traverse_kernel<true, false>), pb, tb, 0, st, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+                else hipLaunchKernelGGL((dev::wf_traverse_kernel<false, false>), pb, tb, 0, st, V, W, r, ctrs, t_refill, t_batch, l_refill, l_batch, dyn256, lds_limit);
+            }
+            if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * ((size_t)r * pipes + h) + 1], st));
+            if (!spill && V.n_lights) hipLaunchKernelGGL(dev::wf_light_exact_kernel, dim3((unsigned)scene->n_cus), dim3(64), 0, st, V, W, r);
+            hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks[h]), dim3(256), 0, st, V, R, W, r, ctrs);
+        }
     }
     HIP_CHECK(hipGetLastError());
+    if (pipes > 1)
+        for (int h = 0; h < pipes; h++) {
+            HIP_CHECK(hipEventRecord(scene->ev_join[h], sp[h]));
+            HIP_CHECK(hipStreamWaitEvent(stream, scene->ev_join[h], 0));
+        }
 }
 
 int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
@@ -534,7 +598,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                     R.partial = scene->d_partial;
                 }
                 launch_wavefront(scene, V8, R, n_work * (uint32_t)streams, stream, count, stats != nullptr);
-                launches = 1 + 2 * (uint32_t)wavefront_rounds(V8, R);
+                launches = (uint32_t)scene->wf_pipes * (1 + 2 * (uint32_t)wavefront_rounds(V8, R));
                 if (streams > 1) {
                     hipLaunchKernelGGL(dev::wf_reduce_streams_kernel, dim3((R.n_pixslots + 255u) / 256u), dim3(256), 0, stream, R);
                     HIP_CHECK(hipGetLastError());
@@ -580,9 +644,14 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
             size_t rounds = wavefront_rounds(V8, R);
-            std::vector<uint32_t> ctr((rounds + 2) * WF_CTR);
+            std::vector<uint32_t> ctr(scene->wf_ctr_block * scene->wf_pipes);
             HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
-            for (size_t r = 0; r < rounds; r++) { h_cnt[0] += ctr[WF_CTR * r]; if (scene->info.n_lights) { h_cnt[1] += ctr[WF_CTR * r + 1]; h_cnt[11] += ctr[WF_CTR * r + 4]; } }
+            for (int h = 0; h < scene->wf_pipes; h++)
+                for (size_t r = 0; r < rounds; r++) {
+                    const uint32_t *c = ctr.data() + (size_t)h * scene->wf_ctr_block + WF_CTR * r;
+                    h_cnt[0] += c[0];
+                    if (scene->info.n_lights) { h_cnt[1] += c[1]; h_cnt[11] += c[4]; }
+                }
             h_cnt[0] -= h_cnt[10]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
         }
         if (count && getenv("RTAMD_DEBUG_COUNTERS"))
@@ -600,8 +669,9 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             if (use_wavefront && blocks) {
                 size_t rounds = wavefront_rounds(V8, R);
                 double sum = 0;
-                for (size_t r = 0; r < rounds; r++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * r], scene->ev_pool[2 * r + 1])); sum += e; }
-                stats->dominant_kernel_ms = sum; stats->dominant_kernel_launches = (uint32_t)rounds;
+                const size_t n_launch = rounds * (size_t)scene->wf_pipes; // with more than one pipeline a launch shares the GPU with the other pipelines' kernels
+                for (size_t r = 0; r < n_launch; r++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * r], scene->ev_pool[2 * r + 1])); sum += e; }
+                stats->dominant_kernel_ms = sum; stats->dominant_kernel_launches = (uint32_t)n_launch;
             } else { stats->dominant_kernel_ms = ms; stats->dominant_kernel_launches = launches; }
             // pixels of this shard that lie inside the image
             uint64_t px = 0;

@@ -164,3 +164,32 @@ def test_empty_scenes_render_the_background(rt, tmp_path):
         rgb, _, _ = scene.render(w, h, max(1, spp), integrator=flavor, ray_depth=depth, want_rgb8=False)
         assert np.allclose(rgb, np.array([0.2, 0.4, 0.6], np.float32), rtol=0, atol=1e-6), flavor
         scene.close()
+
+
+@pytest.mark.parametrize("pipes", [2, 3, 4])
+def test_independent_pipelines_do_not_change_pixels(rt, sphere_scene, monkeypatch, pipes):
+    """Large frames are rendered as several independent pipelines (disjoint path slots, one stream each) whose kernels overlap;
+    RTAMD_WF_PIPELINES forces the cut on small frames.  Plain, sharded, spill-variant and throughput-mode renders must not change."""
+    import pin_cases
+    sd = pin_cases.random_triangle_scene(n=400, seed=33)
+    scene = rt.Scene(sd)
+    w, h, spp = 88, 56, 6
+    monkeypatch.setenv("RTAMD_WF_PIPELINES", "1")
+    ref, ref8, st1 = scene.render(w, h, spp, counters=True)
+    shard_ref, _, _ = scene.render(w, h, spp, shard_index=1, shard_count=3, tile=16)
+    thr_ref, _, _ = scene.render(w, h, spp, sample_streams=3)
+    monkeypatch.setenv("RTAMD_WF_PIPELINES", str(pipes))
+    rgb, rgb8, st = scene.render(w, h, spp, counters=True)
+    assert st.launches == pipes * st1.launches
+    assert np.array_equal(rgb, ref, equal_nan=True) and np.array_equal(rgb8, ref8)
+    assert (st.closest_hit_queries, st.light_pdf_queries, st.samples) == (st1.closest_hit_queries, st1.light_pdf_queries, st1.samples)
+    shard, _, _ = scene.render(w, h, spp, shard_index=1, shard_count=3, tile=16)
+    assert np.array_equal(shard, shard_ref, equal_nan=True)
+    thr, _, _ = scene.render(w, h, spp, sample_streams=3)
+    assert np.array_equal(thr, thr_ref, equal_nan=True)
+    monkeypatch.setenv("RTAMD_WF_LDS_STACK", "3")
+    spill, _, _ = scene.render(w, h, spp)
+    assert np.array_equal(spill, ref, equal_nan=True)
+    orc, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
+    assert np.array_equal(rgb, orc, equal_nan=True)
+    scene.close()

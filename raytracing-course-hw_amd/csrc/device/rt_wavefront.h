@@ -264,6 +264,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
     unsigned long long n_nodes = 0, n_tris = 0;
     unsigned long long w_node_iters = 0, w_leaf_phases = 0, w_leaf_lanes = 0, w_refills = 0; // wave-level (lane 0 reports)
+    uint32_t w_iter = 0, ray_start = 0; // COUNT: wave iterations a ray stays in flight -> histogram counters[16 + min(15, iterations / 32)]
     for (;;) {
         unsigned long long idle = __ballot(!active);
         if (idle && (slice.pos < slice.end || !slice.done) && (__popcll(idle) >= refill || idle == ~0ull)) {
@@ -278,6 +279,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 ray = make_ray_inv(o, d);
                 cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f;
                 active = true;
+                if (COUNT) ray_start = w_iter;
             }
         }
         if (!__ballot(active)) break;
@@ -287,7 +289,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
             unsigned long long m_inner = __ballot(inner);
             unsigned long long m_leaf = __ballot(active && (cur & RT_LEAF_BIT));
             if (!m_inner || __popcll(m_leaf) >= leaf_batch) break;
-            if (COUNT) w_node_iters++;
+            if (COUNT) { w_node_iters++; w_iter++; }
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
@@ -305,9 +307,11 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 else if (sp == 0) { // traversal finished: publish the hit
                     wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
                     active = false;
+                    if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
                 } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
             }
         }
+        if (COUNT) w_iter++;
         // phase 2: every lane waiting at a leaf tests its triangles
         if (COUNT) { unsigned long long ml = __ballot(active && (cur & RT_LEAF_BIT)); if (ml) { w_leaf_phases++; w_leaf_lanes += __popcll(ml); } }
         if (active && (cur & RT_LEAF_BIT)) {
@@ -328,6 +332,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
             if (sp == 0) {
                 wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
                 active = false;
+                if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
             } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
         }
     }
@@ -437,6 +442,7 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     unsigned long long n_nodes = 0, n_tris = 0;
+    uint32_t w_iter = 0, ray_start = 0; // COUNT: histogram of in-flight wave iterations per query, counters[32 + ...]
     // Hit j of the finished walk: light index in stack[31-2j], term in stack[30-2j] (ascending indices); the bottom of the
     // column is free by then and holds the separation depths while the terms are merged.
     auto finish = [&]() {
@@ -488,12 +494,14 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
                 ray = make_ray_inv(o, d);
                 cur = 0; sp = 0; k = 0; overflow = false;
                 active = true;
+                if (COUNT) ray_start = w_iter;
             }
         }
         if (!__ballot(active)) break;
         for (;;) { // phase 1: inner nodes
             bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= leaf_batch) break;
+            if (COUNT) w_iter++;
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
@@ -505,10 +513,11 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
                 if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
                 else if (h0) cur = c0;
                 else if (h1) cur = c1;
-                else if (sp == 0) finish();
+                else if (sp == 0) { finish(); if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[32 + (b > 15u ? 15u : b)], 1ull); } }
                 else cur = stack[--sp][lane];
             }
         }
+        if (COUNT) w_iter++;
         if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
             if (cur != RT_EMPTY_LEAF) {
                 uint32_t i = cur & ~RT_LEAF_BIT;
@@ -524,7 +533,7 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
                     i++;
                 }
             }
-            if (sp == 0) finish();
+            if (sp == 0) { finish(); if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[32 + (b > 15u ? 15u : b)], 1ull); } }
             else cur = stack[--sp][lane];
         }
     }

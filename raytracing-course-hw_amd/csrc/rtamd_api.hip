@@ -195,7 +195,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s->flavor = RT_INTEGRATOR_HW3;
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
-            HIP_CHECK(hipMalloc((void **)&s->d_counters, 128));
+            HIP_CHECK(hipMalloc((void **)&s->d_counters, 512));
             s->allocations.push_back(s->d_counters);
             HIP_CHECK(hipEventCreate(&s->ev_start));
             HIP_CHECK(hipEventCreate(&s->ev_stop));
@@ -237,7 +237,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s->flavor = RT_INTEGRATOR_HW6;
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
-            HIP_CHECK(hipMalloc((void **)&s->d_counters, 128));
+            HIP_CHECK(hipMalloc((void **)&s->d_counters, 512));
             s->allocations.push_back(s->d_counters);
             HIP_CHECK(hipEventCreate(&s->ev_start));
             HIP_CHECK(hipEventCreate(&s->ev_stop));
@@ -291,7 +291,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         V.tan_fov_y = (float)std::tan((double)(desc->camera.fov_y / 2)); // scene.cpp:180 (host libm, like the reference)
         HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
         s->allocations.push_back(s->d_work_counter);
-        HIP_CHECK(hipMalloc((void **)&s->d_counters, 128));
+        HIP_CHECK(hipMalloc((void **)&s->d_counters, 512));
         s->allocations.push_back(s->d_counters);
         HIP_CHECK(hipEventCreate(&s->ev_start));
         HIP_CHECK(hipEventCreate(&s->ev_stop));
@@ -558,7 +558,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             if ((uint64_t)n_work * 64u * (uint64_t)streams >= 0x40000000ull) return fail(RT_ERR_LIMIT, "rt_render: too many path slots (pixels of this shard x sample_streams)");
         }
         HIP_CHECK(hipMemsetAsync(scene->d_work_counter, 0, 4, stream));
-        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 128, stream));
+        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 512, stream));
         uint32_t blocks = (uint32_t)scene->n_cus * 16u;
         if (blocks > n_work) blocks = n_work;
         // Kernel organisation: "wavefront" (default) or the single persistent "megakernel" (RTAMD_KERNEL=mega,
@@ -639,8 +639,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipEventRecord(scene->ev_stop, stream));
         if (own_rgb) HIP_CHECK(hipMemcpyAsync(out_rgb, d_rgb, elems * sizeof(float), hipMemcpyDeviceToHost, stream));
         if (own_rgb8) HIP_CHECK(hipMemcpyAsync(out_rgb8, d_rgb8, elems, hipMemcpyDeviceToHost, stream));
-        unsigned long long h_cnt[16] = {0};
-        if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 128, hipMemcpyDeviceToHost, stream));
+        unsigned long long h_cnt[64] = {0};
+        if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 512, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
             size_t rounds = wavefront_rounds(V8, R);
@@ -653,6 +653,13 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                     if (scene->info.n_lights) { h_cnt[1] += c[1]; h_cnt[11] += c[4]; }
                 }
             h_cnt[0] -= h_cnt[10]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
+        }
+        if (count && use_wavefront && getenv("RTAMD_DEBUG_COUNTERS")) { // wave iterations a query stays in flight, buckets of 32
+            fprintf(stderr, "[rtamd] closest-hit queries by in-flight wave iterations (x32):");
+            for (int b = 0; b < 16; b++) fprintf(stderr, " %llu", h_cnt[16 + b]);
+            fprintf(stderr, "\n[rtamd] light queries by in-flight wave iterations (x32):");
+            for (int b = 0; b < 16; b++) fprintf(stderr, " %llu", h_cnt[32 + b]);
+            fprintf(stderr, "\n");
         }
         if (count && getenv("RTAMD_DEBUG_COUNTERS"))
             fprintf(stderr, "[rtamd] light queries finished by the exact kernel: %llu of %llu; trace kernel: wave node-iterations %llu, leaf phases %llu (lanes %llu), refills %llu; lane node visits %llu, tri tests %llu\n",

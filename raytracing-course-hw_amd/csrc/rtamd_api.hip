@@ -679,6 +679,20 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 const size_t n_launch = rounds * (size_t)scene->wf_pipes; // with more than one pipeline a launch shares the GPU with the other pipelines' kernels
                 for (size_t r = 0; r < n_launch; r++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * r], scene->ev_pool[2 * r + 1])); sum += e; }
                 stats->dominant_kernel_ms = sum; stats->dominant_kernel_launches = (uint32_t)n_launch;
+                if (const char *path = getenv("RTAMD_DUMP_ROUNDS")) { // diagnostic: per launch of the traverse kernel its queue lengths and duration
+                    std::vector<uint32_t> ctr(scene->wf_ctr_block * scene->wf_pipes);
+                    HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
+                    if (FILE *f = fopen(path, "a")) { // appended: one block per render
+                        fprintf(f, "round,pipeline,closest_hit_queries,light_queries,traverse_ms\n");
+                        for (size_t r = 0; r < rounds; r++)
+                            for (int h = 0; h < scene->wf_pipes; h++) {
+                                float e = 0; (void)hipEventElapsedTime(&e, scene->ev_pool[2 * (r * scene->wf_pipes + h)], scene->ev_pool[2 * (r * scene->wf_pipes + h) + 1]);
+                                const uint32_t *c = ctr.data() + (size_t)h * scene->wf_ctr_block + WF_CTR * r;
+                                fprintf(f, "%zu,%d,%u,%u,%.4f\n", r, h, c[0], c[1], e);
+                            }
+                        fclose(f);
+                    }
+                }
             } else { stats->dominant_kernel_ms = ms; stats->dominant_kernel_launches = launches; }
             // pixels of this shard that lie inside the image
             uint64_t px = 0;

@@ -567,6 +567,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
         if (scene->info.bvh_depth > WF_STACK + WF_OVF || scene->info.light_bvh_depth > 64 || scene->info.n_triangles >= 0x40000000u) use_wavefront = false; // light depth: 64-bit frame mask
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
+        if (R.samples / streams >= (1 << 26)) use_wavefront = false; // the path record keeps the sample index in 26 bits
         if (streams > 1 && !use_wavefront) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 needs the wavefront kernels (RTAMD_KERNEL=mega or a tree beyond their limits is in effect)");
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
         if (txt_scene && scene->txt_has_triangles && p->integrator != RT_INTEGRATOR_HW5) return fail(RT_ERR_INVALID_ARG, "rt_render: a .txt scene with TRIANGLE figures renders with RT_INTEGRATOR_HW5 only");
@@ -582,6 +583,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         SceneView V8 = scene->view; // per-render copy: the hw7 replay switches are render parameters, not scene state
         if (hw7) { V8.hw7 = 1; V8.last_level_emission_only = 0; V8.env_image = -1; }
         uint32_t launches = 0;
+        bool time_trace = false;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
             if (use_wavefront) {
@@ -597,7 +599,9 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                     }
                     R.partial = scene->d_partial;
                 }
-                launch_wavefront(scene, V8, R, n_work * (uint32_t)streams, stream, count, stats != nullptr);
+                // every traverse launch is bracketed by events when stats are wanted -- up to 64 k rounds (e.g. 10,922 spp at depth 6)
+                time_trace = stats != nullptr && wavefront_rounds(V8, R) * (size_t)wavefront_pipelines(n_work * (uint32_t)streams) <= 65536;
+                launch_wavefront(scene, V8, R, n_work * (uint32_t)streams, stream, count, time_trace);
                 launches = (uint32_t)scene->wf_pipes * (1 + 2 * (uint32_t)wavefront_rounds(V8, R));
                 if (streams > 1) {
                     hipLaunchKernelGGL(dev::wf_reduce_streams_kernel, dim3((R.n_pixslots + 255u) / 256u), dim3(256), 0, stream, R);
@@ -673,7 +677,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->kernel_ms = ms;
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
-            if (use_wavefront && blocks) {
+            if (use_wavefront && blocks && time_trace) {
                 size_t rounds = wavefront_rounds(V8, R);
                 double sum = 0;
                 const size_t n_launch = rounds * (size_t)scene->wf_pipes; // with more than one pipeline a launch shares the GPU with the other pipelines' kernels

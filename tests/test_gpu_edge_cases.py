@@ -193,3 +193,14 @@ def test_independent_pipelines_do_not_change_pixels(rt, sphere_scene, monkeypatc
     orc, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
     assert np.array_equal(rgb, orc, equal_nan=True)
     scene.close()
+
+
+def test_more_rounds_than_the_per_launch_event_pool(rt, sphere_scene):
+    """12,000 spp at depth 6 = 72,000 wavefront rounds: beyond 65,536 rounds the driver stops bracketing every traverse launch with
+    HIP events (rt_stats.dominant_kernel_ms then falls back to the whole kernel time); pixels are unaffected."""
+    scene = rt.Scene(sphere_scene)
+    rgb, rgb8, st = scene.render(8, 8, 12000)
+    scene.close()
+    ref, ref8, _ = oracle_lib.Hw8Oracle(sphere_scene).render(8, 8, 12000)
+    assert st.launches == 1 + 2 * 72000 and st.dominant_kernel_launches == st.launches and st.dominant_kernel_ms == st.kernel_ms
+    assert np.array_equal(rgb, ref, equal_nan=True) and np.array_equal(rgb8, ref8)

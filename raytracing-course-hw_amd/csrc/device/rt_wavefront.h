@@ -282,13 +282,16 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 if (COUNT) ray_start = w_iter;
             }
         }
-        if (!__ballot(active)) break;
+        const unsigned long long m_active = __ballot(active);
+        if (!m_active) break;
+        // A thinly populated wave (the drain of a launch, small frames) does not make leaf lanes wait for 20 companions.
+        const int lb = min(leaf_batch & 255, (__popcll(m_active) * (leaf_batch >> 16) + 255) >> 8); // a share of the active lanes, in 1/256
         // phase 1: inner nodes
         for (;;) {
             bool inner = active && !(cur & RT_LEAF_BIT);
             unsigned long long m_inner = __ballot(inner);
             unsigned long long m_leaf = __ballot(active && (cur & RT_LEAF_BIT));
-            if (!m_inner || __popcll(m_leaf) >= leaf_batch) break;
+            if (!m_inner || __popcll(m_leaf) >= lb) break;
             if (COUNT) { w_node_iters++; w_iter++; }
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
@@ -373,12 +376,14 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 active = true;
             }
         }
-        if (!__ballot(active)) break;
+        const unsigned long long m_active = __ballot(active);
+        if (!m_active) break;
+        const int lb = min(leaf_batch & 255, (__popcll(m_active) * (leaf_batch >> 16) + 255) >> 8);
         // phase 1: node steps and (cheap) return steps, until enough lanes wait at a leaf
         for (;;) {
             bool at_leaf = active && descending && (cur & RT_LEAF_BIT);
             bool busy = active && !at_leaf;
-            if (!__ballot(busy) || __popcll(__ballot(at_leaf)) >= leaf_batch) break;
+            if (!__ballot(busy) || __popcll(__ballot(at_leaf)) >= lb) break;
             if (busy) {
                 if (descending) {
                     const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
@@ -497,10 +502,12 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
                 if (COUNT) ray_start = w_iter;
             }
         }
-        if (!__ballot(active)) break;
+        const unsigned long long m_active = __ballot(active);
+        if (!m_active) break;
+        const int lb = min(leaf_batch & 255, (__popcll(m_active) * (leaf_batch >> 16) + 255) >> 8); // a share of the active lanes, in 1/256
         for (;;) { // phase 1: inner nodes
             bool inner = active && !(cur & RT_LEAF_BIT);
-            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= leaf_batch) break;
+            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) w_iter++;
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);

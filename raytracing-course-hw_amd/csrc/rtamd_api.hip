@@ -442,8 +442,11 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     if (const char *e = getenv("RTAMD_WF_STEAL_CHUNK")) dyn256 |= ((atoi(e) > 0 ? atoi(e) : 64) & 255) << 8; // tuning: items per dynamic chunk (default 64)
     if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) dyn256 |= (a << 16) | (b << 24); } // cost weights closest-hit : light query
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
-    const int t_refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL), t_batch = env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH);
-    const int l_refill = env_int("RTAMD_LIGHT_REFILL", WF_REFILL), l_batch = env_int("RTAMD_LIGHT_LEAF_BATCH", WF_LEAF_BATCH);
+    // leaf batch: lanes waiting at a leaf start their triangle tests when 20 of them wait -- or, in a thinly populated wave, a share
+    // of the active lanes (RTAMD_WF_LEAF_SHARE_256, default 112/256; sweep: tools/tuning/sweep_leaf_share.sh); packed as batch | share << 16
+    const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
+    const int t_refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL), t_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    const int l_refill = env_int("RTAMD_LIGHT_REFILL", WF_REFILL), l_batch = (env_int("RTAMD_LIGHT_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
     unsigned long long *ctrs = count ? scene->d_counters : nullptr;
     if (time_trace) while (scene->ev_pool.size() < 2 * rounds * pipes) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
 

@@ -265,6 +265,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
     unsigned long long n_nodes = 0, n_tris = 0;
     unsigned long long w_node_iters = 0, w_leaf_phases = 0, w_leaf_lanes = 0, w_refills = 0; // wave-level (lane 0 reports)
     uint32_t w_iter = 0, ray_start = 0; // COUNT: wave iterations a ray stays in flight -> histogram counters[16 + min(15, iterations / 32)]
+    const bool hist = COUNT && counters && counters[15] != 0; // the host sets counters[15] when the histogram is wanted (one global atomic per query)
     for (;;) {
         unsigned long long idle = __ballot(!active);
         if (idle && (slice.pos < slice.end || !slice.done) && (__popcll(idle) >= refill || idle == ~0ull)) {
@@ -310,7 +311,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 else if (sp == 0) { // traversal finished: publish the hit
                     wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
                     active = false;
-                    if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
+                    if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
                 } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
             }
         }
@@ -335,7 +336,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
             if (sp == 0) {
                 wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
                 active = false;
-                if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
+                if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
             } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
         }
     }
@@ -448,6 +449,7 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
     RayInv ray = make_ray_inv(o, d);
     unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t w_iter = 0, ray_start = 0; // COUNT: histogram of in-flight wave iterations per query, counters[32 + ...]
+    const bool hist = COUNT && counters && counters[15] != 0;
     // Hit j of the finished walk: light index in stack[31-2j], term in stack[30-2j] (ascending indices); the bottom of the
     // column is free by then and holds the separation depths while the terms are merged.
     auto finish = [&]() {
@@ -520,7 +522,7 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
                 if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
                 else if (h0) cur = c0;
                 else if (h1) cur = c1;
-                else if (sp == 0) { finish(); if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[32 + (b > 15u ? 15u : b)], 1ull); } }
+                else if (sp == 0) { finish(); if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[32 + (b > 15u ? 15u : b)], 1ull); } }
                 else cur = stack[--sp][lane];
             }
         }
@@ -540,7 +542,7 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
                     i++;
                 }
             }
-            if (sp == 0) { finish(); if (COUNT && counters) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[32 + (b > 15u ? 15u : b)], 1ull); } }
+            if (sp == 0) { finish(); if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[32 + (b > 15u ? 15u : b)], 1ull); } }
             else cur = stack[--sp][lane];
         }
     }

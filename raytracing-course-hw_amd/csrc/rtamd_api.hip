@@ -561,7 +561,10 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             if ((uint64_t)n_work * 64u * (uint64_t)streams >= 0x40000000ull) return fail(RT_ERR_LIMIT, "rt_render: too many path slots (pixels of this shard x sample_streams)");
         }
         HIP_CHECK(hipMemsetAsync(scene->d_work_counter, 0, 4, stream));
-        if (count) HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 512, stream));
+        if (count) {
+            HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 512, stream));
+            if (getenv("RTAMD_DEBUG_COUNTERS")) HIP_CHECK(hipMemsetAsync(scene->d_counters + 15, 1, 1, stream)); // asks the counting kernels for the in-flight histograms
+        }
         uint32_t blocks = (uint32_t)scene->n_cus * 16u;
         if (blocks > n_work) blocks = n_work;
         // Kernel organisation: "wavefront" (default) or the single persistent "megakernel" (RTAMD_KERNEL=mega,

@@ -447,6 +447,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
     const int t_refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL), t_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
     const int l_refill = env_int("RTAMD_LIGHT_REFILL", WF_REFILL), l_batch = (env_int("RTAMD_LIGHT_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    const uint32_t shade_per_cu = (uint32_t)env_int("RTAMD_WF_SHADE_BLOCKS_PER_CU", 16); // grid cap of wf_shade_kernel (grid-stride beyond it)
     unsigned long long *ctrs = count ? scene->d_counters : nullptr;
     if (time_trace) while (scene->ev_pool.size() < 2 * rounds * pipes) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
 
@@ -477,7 +478,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
         Wp[h] = W;
         sp[h] = pipes > 1 ? scene->wf_streams[h] : stream;
         shade_blocks[h] = (W.n_slots + 255u) / 256u;
-        if (shade_blocks[h] > (uint32_t)scene->n_cus * 16u) shade_blocks[h] = (uint32_t)scene->n_cus * 16u;
+        if (shade_blocks[h] > (uint32_t)scene->n_cus * shade_per_cu) shade_blocks[h] = (uint32_t)scene->n_cus * shade_per_cu;
         first += groups;
     }
     if (pipes > 1) {

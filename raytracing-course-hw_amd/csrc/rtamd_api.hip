@@ -440,7 +440,9 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     int dyn256 = 64;                                                   // share of each queue (of 256) handed out dynamically at the tail
     if (const char *e = getenv("RTAMD_WF_DYNAMIC_256")) dyn256 = atoi(e) < 0 ? 0 : (atoi(e) > 255 ? 255 : atoi(e));
     if (const char *e = getenv("RTAMD_WF_STEAL_CHUNK")) dyn256 |= ((atoi(e) > 0 ? atoi(e) : 64) & 255) << 8; // tuning: items per dynamic chunk (default 64)
-    if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) dyn256 |= (a << 16) | (b << 24); } // cost weights closest-hit : light query
+    int split_a = 7, split_b = 8; // cost weights closest-hit : light query for the block split (two sweeps: 7:8 is ~1 % ahead of 1:1 and 8:7)
+    if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) { split_a = a; split_b = b; } }
+    dyn256 |= (split_a << 16) | (split_b << 24);
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
     // leaf batch: lanes waiting at a leaf start their triangle tests when 20 of them wait -- or, in a thinly populated wave, a share
     // of the active lanes (RTAMD_WF_LEAF_SHARE_256, default 112/256; sweep: tools/tuning/sweep_leaf_share.sh); packed as batch | share << 16

@@ -142,7 +142,7 @@ RT_DEV float light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
 // added in the reference's association by walking the reference tree's index ranges only where hits lie: sum(node) =
 // sum(left) + sum(right), a side without hits contributes the additive identity, a leaf adds its hits in index order.
 #define RT6_MAX_LIGHT_HITS 16
-RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
+RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stack, uint32_t *deep_stack) {
     RayInv ray = make_ray_inv(x, d);
     int sp = 0, k = 0;
     uint32_t hit_idx[RT6_MAX_LIGHT_HITS];
@@ -165,7 +165,7 @@ RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stac
                 Tri6Regs T = load_tri6(S.fast_lights + i);
                 float t; bool inside;
                 if (tri6_test(T, x, d, t, inside)) {
-                    if (k == RT6_MAX_LIGHT_HITS) return light_pdf_sum6(S, x, d, stack); // more hits than kept: the plain reference-order walk
+                    if (k == RT6_MAX_LIGHT_HITS) return light_pdf_sum6(S, x, d, deep_stack); // more hits than kept: the plain reference-order walk
                     F3 yn = normalize(inside ? neg(T.n) : T.n);                  // primitives.cpp:31
                     F3 y = x + t * d;
                     hit_idx[k] = T.ref_index;
@@ -234,7 +234,7 @@ struct Machine6 {
 };
 RT_DEV void machine6_start(Machine6 &M, F3 o, F3 d) { M.fp = 0; M.evaluating = true; M.o = o; M.d = d; M.ret = f3(0.f, 0.f, 0.f); }
 // Returns true when the path is complete (M.ret = getColor of the camera ray).
-RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6 &M, uint32_t *stack) {
+RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6 &M, uint32_t *stack, uint32_t *deep_stack) {
     Frame6 *frames = M.frames;
     int &fp = M.fp;
     const float epsf = 9.99999974737875163555e-05f; // (float)1e-4L
@@ -270,7 +270,7 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
                 if (dot(nd, norma) < 0) { ret = emission; evaluating = false; continue; }       // scene.cpp:64-66
                 float pdf = 0.f;
                 pdf += smax(0.f, dot(nd, norma) / RT_PI_F);                                     // distributions.h:55-58
-                if (S.n_components == 2) pdf += light_pdf_sum6_fast(S, xo, nd, stack) / (float)S.n_lights;
+                if (S.n_components == 2) pdf += light_pdf_sum6_fast(S, xo, nd, stack, deep_stack) / (float)S.n_lights;
                 pdf = pdf / (float)S.n_components;
                 float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)dot(nd, norma));       // scene.cpp:69
                 f.kind = F6_MUL; f.emission = emission; f.mult = k * color;
@@ -318,9 +318,17 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
     return false;
 }
 
+// LDS_STACK: the traversal stacks of the closest-hit walk and of the fast light walk live in LDS (one column of RT6_LDS_STACK
+// entries per lane, odd stride: conflict-free) instead of scratch memory; the host selects it when both of the library's own
+// trees are shallow enough.  The reference-order light walk (only after more than 16 hits) keeps its deep private stack.
+#define RT6_LDS_STACK 48
+#define RT6_LDS_STRIDE 49
+template <bool LDS_STACK>
 __global__ __launch_bounds__(64) void render_hw6_kernel(SceneView6 S, RenderView R, uint32_t n_work) {
-    uint32_t stack[RT6_STACK_SIZE];
+    __shared__ uint32_t lds_stack[LDS_STACK ? 64 * RT6_LDS_STRIDE : 1];
+    uint32_t deep_stack[RT6_STACK_SIZE];
     const int lane = threadIdx.x & 63;
+    uint32_t *stack = LDS_STACK ? lds_stack + lane * RT6_LDS_STRIDE : deep_stack;
     const uint32_t n_slots = n_work * 64u;   // pixel slots in the tile order of slot_to_pixel()
     Machine6 M;
     machine6_start(M, f3(0.f, 0.f, 0.f), f3(0.f, 0.f, 1.f));
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(64) void render_hw6_kernel(SceneView6 S, RenderView
             }
         }
         if (!__ballot(have_pixel)) { if (exhausted) break; else continue; }
-        if (have_pixel && machine6_step(S, R.ray_depth, rng, M, stack)) {
+        if (have_pixel && machine6_step(S, R.ray_depth, rng, M, stack, deep_stack)) {
             color = color + M.ret;                                                               // scene.cpp:113
             if (++s < R.samples) camera_ray();
             else {

@@ -74,6 +74,7 @@ struct rt_scene {
     SceneView5 view5{};
     bool txt_has_triangles = false; // TRIANGLE figures exist only in the hw5 grammar: such a scene renders with RT_INTEGRATOR_HW5 only
     int flavor = RT_INTEGRATOR_HW8; // which integrator this scene was prepared for
+    bool hw6_lds_stack = false;
     std::vector<void *> allocations;
     rt_scene_info info{};
     std::vector<uint32_t> light_order;
@@ -213,6 +214,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             if (P6.bvh_depth > RT6_STACK_SIZE - 2 || P6.light_bvh_depth > RT6_STACK_SIZE - 2 || P6.fast_light_bvh_depth > RT6_STACK_SIZE - 2)
                 return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P6.bvh_depth) + "/" +
                                               std::to_string(P6.light_bvh_depth) + ")");
+            s->hw6_lds_stack = P6.bvh_depth <= RT6_LDS_STACK && P6.fast_light_bvh_depth <= RT6_LDS_STACK; // both own trees fit the LDS stack columns
             uint64_t bytes = 0;
             SceneView6 &V = s->view6;
             auto keep = [&](auto *p) { s->allocations.push_back((void *)p); return p; };
@@ -639,7 +641,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
             } else if (scene->flavor == RT_INTEGRATOR_HW6) {
-                hipLaunchKernelGGL(dev::render_hw6_kernel, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
+                if (scene->hw6_lds_stack && !getenv("RTAMD_HW6_SCRATCH_STACK")) hipLaunchKernelGGL(dev::render_hw6_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
+                else hipLaunchKernelGGL(dev::render_hw6_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
             } else {

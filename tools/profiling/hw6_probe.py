@@ -1,5 +1,5 @@
 import sys, importlib
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 rt = importlib.import_module("raytracing-course-hw_amd")
 import pin_cases
 sd = pin_cases.load_hw6("practice6_2")

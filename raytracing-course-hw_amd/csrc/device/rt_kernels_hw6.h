@@ -44,37 +44,54 @@ RT_DEV bool tri6_test(const Tri6Regs &T, F3 o, F3 d, float &t, bool &inside) {
 
 struct Hit6 { int slot; float t; bool inside; uint32_t ref; };
 
+// Wave-synchronous "while-while" walk: the lanes of the wave that are in this call step through inner nodes together until
+// enough of them (a share of the walking lanes, at most RT6_LEAF_BATCH) wait at a leaf, then those test their triangles
+// together -- the two code paths are no longer interleaved lane by lane.  The result does not depend on the order (tie rule).
+#define RT6_LEAF_BATCH 20
 RT_DEV Hit6 closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack) {
     Hit6 best; best.slot = -1; best.t = RT_T_MAX; best.inside = false; best.ref = 0xFFFFFFFFu;
     RayInv ray = make_ray_inv(o, d);
     int sp = 0;
     uint32_t cur = 0;
+    bool walking = true;
     for (;;) {
-        if (!(cur & RT_LEAF_BIT)) {
-            const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
-            float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
-            float n0, n1;
-            bool h0 = slab_test(lo0, hi0, ray, best.t, n0);
-            bool h1 = slab_test(lo1, hi1, ray, best.t, n1);
-            uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-            if (h0 & h1) { bool swap = n1 < n0; stack[sp++] = swap ? c0 : c1; cur = swap ? c1 : c0; continue; }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else if (cur != RT_EMPTY_LEAF) {
-            uint32_t i = cur & ~RT_LEAF_BIT;
-            for (;;) {
-                Tri6Regs T = load_tri6(S.tris + i);
-                float t; bool inside;
-                // reference tie rule: smallest t, equal t -> lowest index in the reference's figure order
-                if (tri6_test(T, o, d, t, inside) && (t < best.t || (t == best.t && T.ref_index < best.ref))) {
-                    best.t = t; best.inside = inside; best.slot = (int)i; best.ref = T.ref_index;
-                }
-                if (T.last) break;
-                i++;
+        const unsigned long long m_walk = __ballot(walking);
+        if (!m_walk) break;
+        const int lb = min(RT6_LEAF_BATCH, (int)((__popcll(m_walk) * 112 + 255) >> 8));
+        for (;;) { // phase 1: inner nodes
+            const bool inner = walking && !(cur & RT_LEAF_BIT);
+            if (!__ballot(inner) || (int)__popcll(__ballot(walking && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (inner) {
+                const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
+                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+                float n0, n1;
+                bool h0 = slab_test(lo0, hi0, ray, best.t, n0);
+                bool h1 = slab_test(lo1, hi1, ray, best.t, n1);
+                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+                if (h0 & h1) { bool swap = n1 < n0; stack[sp++] = swap ? c0 : c1; cur = swap ? c1 : c0; }
+                else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp == 0) walking = false;
+                else cur = stack[--sp];
             }
         }
-        if (sp == 0) break;
-        cur = stack[--sp];
+        if (walking && (cur & RT_LEAF_BIT)) { // phase 2: leaves
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    Tri6Regs T = load_tri6(S.tris + i);
+                    float t; bool inside;
+                    // reference tie rule: smallest t, equal t -> lowest index in the reference's figure order
+                    if (tri6_test(T, o, d, t, inside) && (t < best.t || (t == best.t && T.ref_index < best.ref))) {
+                        best.t = t; best.inside = inside; best.slot = (int)i; best.ref = T.ref_index;
+                    }
+                    if (T.last) break;
+                    i++;
+                }
+            }
+            if (sp == 0) walking = false;
+            else cur = stack[--sp];
+        }
     }
     return best;
 }
@@ -148,37 +165,51 @@ RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stac
     uint32_t hit_idx[RT6_MAX_LIGHT_HITS];
     float hit_term[RT6_MAX_LIGHT_HITS];
     uint32_t cur = 0;
-    for (;;) {
-        if (!(cur & RT_LEAF_BIT)) {
-            const float4 *q = reinterpret_cast<const float4 *>(S.fast_light_nodes + cur);
-            float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
-            float n0, n1;
-            bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
-            bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
-            uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-            if (h0 & h1) { stack[sp++] = c1; cur = c0; continue; }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else if (cur != RT_EMPTY_LEAF) {
-            uint32_t i = cur & ~RT_LEAF_BIT;
-            for (;;) {
-                Tri6Regs T = load_tri6(S.fast_lights + i);
-                float t; bool inside;
-                if (tri6_test(T, x, d, t, inside)) {
-                    if (k == RT6_MAX_LIGHT_HITS) return light_pdf_sum6(S, x, d, deep_stack); // more hits than kept: the plain reference-order walk
-                    F3 yn = normalize(inside ? neg(T.n) : T.n);                  // primitives.cpp:31
-                    F3 y = x + t * d;
-                    hit_idx[k] = T.ref_index;
-                    hit_term[k] = T.point_prob * len2(x - y) / fabsf(dot(d, yn)); // distributions.h:116-118
-                    k++;
-                }
-                if (T.last) break;
-                i++;
+    bool walking = true, too_many = false;
+    for (;;) { // wave-synchronous while-while walk, as in closest_hit6
+        const unsigned long long m_walk = __ballot(walking);
+        if (!m_walk) break;
+        const int lb = min(RT6_LEAF_BATCH, (int)((__popcll(m_walk) * 112 + 255) >> 8));
+        for (;;) { // phase 1: inner nodes
+            const bool inner = walking && !(cur & RT_LEAF_BIT);
+            if (!__ballot(inner) || (int)__popcll(__ballot(walking && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (inner) {
+                const float4 *q = reinterpret_cast<const float4 *>(S.fast_light_nodes + cur);
+                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+                float n0, n1;
+                bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
+                bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+                if (h0 & h1) { stack[sp++] = c1; cur = c0; }
+                else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp == 0) walking = false;
+                else cur = stack[--sp];
             }
         }
-        if (sp == 0) break;
-        cur = stack[--sp];
+        if (walking && (cur & RT_LEAF_BIT)) { // phase 2: leaves
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    Tri6Regs T = load_tri6(S.fast_lights + i);
+                    float t; bool inside;
+                    if (tri6_test(T, x, d, t, inside)) {
+                        if (k == RT6_MAX_LIGHT_HITS) { too_many = true; break; }
+                        F3 yn = normalize(inside ? neg(T.n) : T.n);                  // primitives.cpp:31
+                        F3 y = x + t * d;
+                        hit_idx[k] = T.ref_index;
+                        hit_term[k] = T.point_prob * len2(x - y) / fabsf(dot(d, yn)); // distributions.h:116-118
+                        k++;
+                    }
+                    if (T.last) break;
+                    i++;
+                }
+            }
+            if (sp == 0 || too_many) walking = false;
+            else cur = stack[--sp];
+        }
     }
+    if (too_many) return light_pdf_sum6(S, x, d, deep_stack); // more hits than kept: the plain reference-order walk
     if (k == 0) return 0.f;
     if (k == 1) return hit_term[0];
     if (k == 2) return hit_term[0] + hit_term[1];

@@ -47,7 +47,12 @@ struct Hit6 { int slot; float t; bool inside; uint32_t ref; };
 // Wave-synchronous "while-while" walk: the lanes of the wave that are in this call step through inner nodes together until
 // enough of them (a share of the walking lanes, at most RT6_LEAF_BATCH) wait at a leaf, then those test their triangles
 // together -- the two code paths are no longer interleaved lane by lane.  The result does not depend on the order (tie rule).
+#ifndef RT6_LEAF_BATCH
 #define RT6_LEAF_BATCH 20
+#endif
+#ifndef RT6_LEAF_SHARE
+#define RT6_LEAF_SHARE 112 // of 256: share of the walking lanes that must wait at a leaf
+#endif
 RT_DEV Hit6 closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack) {
     Hit6 best; best.slot = -1; best.t = RT_T_MAX; best.inside = false; best.ref = 0xFFFFFFFFu;
     RayInv ray = make_ray_inv(o, d);
@@ -57,7 +62,7 @@ RT_DEV Hit6 closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack) {
     for (;;) {
         const unsigned long long m_walk = __ballot(walking);
         if (!m_walk) break;
-        const int lb = min(RT6_LEAF_BATCH, (int)((__popcll(m_walk) * 112 + 255) >> 8));
+        const int lb = min(RT6_LEAF_BATCH, (int)((__popcll(m_walk) * RT6_LEAF_SHARE + 255) >> 8));
         for (;;) { // phase 1: inner nodes
             const bool inner = walking && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || (int)__popcll(__ballot(walking && (cur & RT_LEAF_BIT))) >= lb) break;
@@ -169,7 +174,7 @@ RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stac
     for (;;) { // wave-synchronous while-while walk, as in closest_hit6
         const unsigned long long m_walk = __ballot(walking);
         if (!m_walk) break;
-        const int lb = min(RT6_LEAF_BATCH, (int)((__popcll(m_walk) * 112 + 255) >> 8));
+        const int lb = min(RT6_LEAF_BATCH, (int)((__popcll(m_walk) * RT6_LEAF_SHARE + 255) >> 8));
         for (;;) { // phase 1: inner nodes
             const bool inner = walking && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || (int)__popcll(__ballot(walking && (cur & RT_LEAF_BIT))) >= lb) break;

@@ -356,11 +356,16 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
 
 // LDS_STACK: the traversal stacks of the closest-hit walk and of the fast light walk live in LDS (one column of RT6_LDS_STACK
 // entries per lane, odd stride: conflict-free) instead of scratch memory; the host selects it when both of the library's own
-// trees are shallow enough.  The reference-order light walk (only after more than 16 hits) keeps its deep private stack.
-#define RT6_LDS_STACK 48
-#define RT6_LDS_STRIDE 49
+// trees are at most that deep.  The reference-order light walk (only after more than 16 hits) keeps its deep private stack.
+#ifndef RT6_LDS_STACK
+#define RT6_LDS_STACK 36   // 9.5 KB per wave: 16 waves per CU; measured on config 3 (stack entries / waves per SIMD): 36/4 61.6, 32/5 58.7, 40/4 57.6, 28/6 55.1, 48/3 55.5 Msamples/s
+#endif
+#define RT6_LDS_STRIDE (RT6_LDS_STACK + 1)
+#ifndef RT6_MIN_WAVES
+#define RT6_MIN_WAVES 4    // waves per SIMD the register allocation aims at (128 VGPR, some spills)
+#endif
 template <bool LDS_STACK>
-__global__ __launch_bounds__(64) void render_hw6_kernel(SceneView6 S, RenderView R, uint32_t n_work) {
+__global__ __launch_bounds__(64, RT6_MIN_WAVES) void render_hw6_kernel(SceneView6 S, RenderView R, uint32_t n_work) {
     __shared__ uint32_t lds_stack[LDS_STACK ? 64 * RT6_LDS_STRIDE : 1];
     uint32_t deep_stack[RT6_STACK_SIZE];
     const int lane = threadIdx.x & 63;

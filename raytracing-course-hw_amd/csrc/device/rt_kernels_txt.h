@@ -246,7 +246,10 @@ RT_DEV F3 trace_tree3(const SceneViewTxt &S, int ray_depth, Rng &rng, F3 o, F3 d
     return ret;
 }
 
-__global__ __launch_bounds__(64) void render_hw3_kernel(SceneViewTxt S, RenderView R, float tan_fov_y, uint32_t n_work) {
+#ifndef RT3_MIN_WAVES
+#define RT3_MIN_WAVES 4 // waves per SIMD the register allocation aims at; config 2: 1 -> 14.1 ms, 3 -> 14.3, 4 -> 11.9, 5 -> 12.0, 6 -> 12.2, 8 -> 17.6
+#endif
+__global__ __launch_bounds__(64, RT3_MIN_WAVES) void render_hw3_kernel(SceneViewTxt S, RenderView R, float tan_fov_y, uint32_t n_work) {
     const int lane = threadIdx.x & 63;
     const int sub_x = R.tile_w >> 3, sub_per_tile = sub_x * (R.tile_h >> 3);
     for (;;) {

@@ -261,6 +261,11 @@ def write_ppm(path, rgb8):
     _check(lib.rt_write_ppm(os.fsencode(path), rgb8.shape[1], rgb8.shape[0], rgb8.ctypes.data))
 
 
+def dominant_kernel_name(st):
+    """Name of the kernel rt_stats.dominant_kernel_ms / _launches refer to (for the hw8 / hw7 integrators)."""
+    return "wf_traverse_kernel" if st.dominant_kernel_launches > 1 else "render_hw8_kernel"
+
+
 def make_params(width, height, samples, integrator=RT_INTEGRATOR_HW8, ray_depth=0, shard_index=0, shard_count=1,
                 tile=32, flags=0, stream=None, sample_streams=0):
     p = rt_render_params()

@@ -343,7 +343,9 @@ struct Loader {
                 // 5123 (u16) and 5125 (u32) as the reference; 5121 (u8) is an extension (the reference would misread it as u32)
                 size_t isz = ia.componentType == 5123 ? 2 : (ia.componentType == 5121 ? 1 : 4);
                 if (ia.componentType != 5121 && ia.componentType != 5123 && ia.componentType != 5125) throw std::runtime_error("glTF: index componentType must be 5121, 5123 or 5125");
-                const uint8_t *ip = accessor_ptr(pr.indices, isz, n_idx, false); // accessor byteOffset ignored like :258-269
+                // Extension: the index accessor's byteOffset is honoured (the reference ignores it, sceneio.cpp:258-269, and would
+                // read the wrong triangles from a bufferView shared by several index accessors; its shipped scenes all have 0).
+                const uint8_t *ip = accessor_ptr(pr.indices, isz, n_idx, true);
                 const Mat4 &M = node.total;
                 Mat4 NM = M.inverted().transposed();
                 F3 shift = M.apply(F3{0, 0, 0});

@@ -168,3 +168,39 @@ def test_host_preparation_reproduces_reference_figure_and_light_orders(rt, spher
     fo, lo = rt.host_prepare_orders(sd5, rt.RT_INTEGRATOR_HW5)
     ofo, olo = oracle_lib.Hw5Oracle(sd5).orders()
     assert np.array_equal(fo, ofo) and np.array_equal(lo, olo) and len(lo) == 8
+
+
+def test_gltf_index_accessor_byte_offset_is_honoured(rt, tmp_path):
+    """Extension beyond the reference (which ignores the index accessor's byteOffset, hw8/src/sceneio.cpp:258-269): two index
+    accessors packed into ONE bufferView — mesh 0 uses the first 12 indices, mesh 1 the last 12 — must load exactly the
+    triangles of the same file written with one tight index view per mesh."""
+    import json
+    import pin_cases
+    tight_path, _ = pin_cases.loader_case(str(tmp_path / "base"))
+    g = json.load(open(tight_path))
+    blob = open(os.path.join(str(tmp_path / "base"), "loader_case.bin"), "rb").read()
+    idx_view = g["bufferViews"][4]
+    prim = g["meshes"][0]["primitives"][0]
+
+    def variant(name, views, accessors):
+        h = json.loads(json.dumps(g))
+        h["bufferViews"] = g["bufferViews"][:4] + views
+        h["accessors"] = g["accessors"][:4] + accessors
+        h["meshes"] = [{"primitives": [dict(prim, indices=4)]}, {"primitives": [dict(prim, indices=5)]}]
+        d = tmp_path / name
+        d.mkdir()
+        (d / "loader_case.bin").write_bytes(blob)
+        json.dump(h, open(d / "scene.gltf", "w"))
+        return rt.load_gltf(str(d / "scene.gltf"))
+
+    off, half = idx_view["byteOffset"], 12
+    shared = variant("shared", [dict(idx_view)],
+                     [{"bufferView": 4, "byteOffset": 0, "componentType": 5123, "count": half, "type": "SCALAR"},
+                      {"bufferView": 4, "byteOffset": 2 * half, "componentType": 5123, "count": half, "type": "SCALAR"}])
+    split = variant("split", [{"buffer": 0, "byteOffset": off, "byteLength": 2 * half}, {"buffer": 0, "byteOffset": off + 2 * half, "byteLength": 2 * half}],
+                    [{"bufferView": 4, "componentType": 5123, "count": half, "type": "SCALAR"},
+                     {"bufferView": 5, "componentType": 5123, "count": half, "type": "SCALAR"}])
+    assert shared.positions.shape == split.positions.shape == (8, 9)
+    for name in ("positions", "normals", "texcoords", "tangents"):
+        assert np.array_equal(getattr(shared, name).view(np.uint32), getattr(split, name).view(np.uint32)), name
+    assert not np.array_equal(shared.positions[:4], shared.positions[4:])  # the two meshes really use different triangles

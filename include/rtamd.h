@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 3
+#define RTAMD_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -176,9 +176,22 @@ typedef struct rt_stats {
     uint64_t closest_hit_queries, light_pdf_queries; /* RT_FLAG_COUNTERS */
     uint64_t node_visits, triangle_tests;            /* RT_FLAG_COUNTERS */
     uint32_t launches;
-    uint32_t dominant_kernel_launches; /* launches of the dominant kernel (wavefront path: wf_trace_kernel) */
+    uint32_t dominant_kernel_launches; /* launches of the dominant kernel (rt_stats.pipeline says which) */
     double dominant_kernel_ms;         /* sum of their HIP-event durations on the launch stream */
+    uint32_t pipeline;                 /* rt_pipeline: how the kernels of this render were organised */
+    uint32_t reserved;
+    uint64_t exact_closest_hits, exact_light_sums; /* RT_PIPELINE_PERSISTENT: queries re-walked with the reference's own box
+                                                      arithmetic (hw8/src/primitives.cpp:29-53,163-165) because the fast walk's
+                                                      answer was not robust against it */
 } rt_stats;
+
+/* Kernel organisations of the hw8 / hw7 integrators (the others are always RT_PIPELINE_SINGLE).  Environment RTAMD_KERNEL =
+ * persistent (default) | wavefront | mega selects; all three replay the same arithmetic. */
+typedef enum rt_pipeline {
+    RT_PIPELINE_SINGLE = 0,     /* one launch of a whole-path kernel: render_hw8_kernel ("mega") and render_hw1..hw6_kernel */
+    RT_PIPELINE_ROUNDS = 1,     /* per bounce round: wf_traverse_kernel (dominant) + wf_shade_kernel */
+    RT_PIPELINE_PERSISTENT = 2  /* pt_persistent_kernel: one launch per frame, per-path dataflow inside each workgroup */
+} rt_pipeline;
 
 typedef struct rt_scene rt_scene;
 

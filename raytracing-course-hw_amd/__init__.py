@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "librtamd.so")
 RT_INTEGRATOR_HW1, RT_INTEGRATOR_HW2, RT_INTEGRATOR_HW3, RT_INTEGRATOR_HW4, RT_INTEGRATOR_HW5 = 1, 2, 3, 4, 5
 RT_INTEGRATOR_HW6, RT_INTEGRATOR_HW7, RT_INTEGRATOR_HW8 = 6, 7, 8
 RT_FLAG_OUT_DEVICE, RT_FLAG_COUNTERS = 1, 2
+RT_PIPELINE_SINGLE, RT_PIPELINE_ROUNDS, RT_PIPELINE_PERSISTENT = 0, 1, 2
 RT_OK = 0
 RT_ERR_NO_DEVICE = -2
 
@@ -80,7 +81,8 @@ class rt_stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("samples", C.c_uint64),
                 ("closest_hit_queries", C.c_uint64), ("light_pdf_queries", C.c_uint64), ("node_visits", C.c_uint64),
                 ("triangle_tests", C.c_uint64), ("launches", C.c_uint32), ("dominant_kernel_launches", C.c_uint32),
-                ("dominant_kernel_ms", C.c_double)]
+                ("dominant_kernel_ms", C.c_double), ("pipeline", C.c_uint32), ("reserved", C.c_uint32),
+                ("exact_closest_hits", C.c_uint64), ("exact_light_sums", C.c_uint64)]
 
 
 class rt_scene_info(C.Structure):
@@ -263,7 +265,7 @@ def write_ppm(path, rgb8):
 
 def dominant_kernel_name(st):
     """Name of the kernel rt_stats.dominant_kernel_ms / _launches refer to (for the hw8 / hw7 integrators)."""
-    return "wf_traverse_kernel" if st.dominant_kernel_launches > 1 else "render_hw8_kernel"
+    return {RT_PIPELINE_ROUNDS: "wf_traverse_kernel", RT_PIPELINE_PERSISTENT: "pt_persistent_kernel"}.get(st.pipeline, "render_hw8_kernel")
 
 
 def make_params(width, height, samples, integrator=RT_INTEGRATOR_HW8, ray_depth=0, shard_index=0, shard_count=1,

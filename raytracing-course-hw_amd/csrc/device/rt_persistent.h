@@ -1,0 +1,661 @@
+// Persistent dataflow form of the hw8 replay path tracer: ONE launch renders the frame, no rounds and no global barrier.
+//
+// The reference's per-pixel loop (hw8/src/scene.cpp:84-177) is a chain of dependent stages per pixel — closest hit
+// (bvh.h:111-142) -> shade / sample (scene.cpp:99-156) -> light-pdf sum (distributions.h:148-165) -> throughput update
+// (scene.cpp:158-164) -> next bounce or next sample — and the chain of one pixel never depends on another pixel's.  The
+// round-based pipeline of rt_wavefront.h runs each stage as a kernel over all pixels and pays a machine-wide drain at every
+// kernel boundary (the launch ends with its longest walk).  Here the dependency is kept PER PATH:
+//
+//   * one 1024-thread workgroup per CU owns a fixed, interleaved share of the pixel slots (8x8 sub-tiles dealt round-robin
+//     to the workgroups); the path records stay in HBM in the layout of rt_wavefront.h, but only this workgroup touches
+//     them, so hand-offs between its waves need workgroup-scope ordering only (one CU, one L1: `s_waitcnt` + LDS);
+//   * the stage a path waits for is one bit per path in an LDS bitmap (need_trace / need_light / need_shade / ...); a wave
+//     that wants work claims set bits with LDS atomics (one word per lane, rotating cursor: round-robin service, no
+//     capacity limit, no ring to overflow);
+//   * every wave picks a role when it is idle: closest-hit walker, light-sum walker or shader, by the populations of the
+//     bitmaps; walkers keep their lanes full by refilling idle lanes from the bitmap; a shader takes up to 64 paths,
+//     finishes their pending bounce, shades the new hit and sets the bits of what each path needs next;
+//   * the speculative pairing of rt_wavefront.h is kept: a bounce's sampled direction is traced for the next hit at the
+//     same time as its light-pdf sum is walked; a 2-bit "pending" field per path joins the two (whoever finishes last sets
+//     need_shade).
+//
+// What this removes: 3 x spp x depth kernel launches, the global queue atomics, the per-round drain (every launch of the round
+// pipeline waited for its longest walk), and the idle memory system during traversal / idle ALUs during shading (the roles
+// overlap on every CU).  A path advances as fast as its own chain allows, which is what lets a small frame (a shard of a
+// multi-GPU render) run near the full rate.
+//
+// Reference-exact box decisions (hw8/src/primitives.cpp:29-53,163-165).  The walkers prune with a cheap conservative test on
+// padded boxes, so they find a superset of the triangles the reference's own slab test lets through.  A hit is accepted
+// as it stands when the hit point lies robustly inside its triangle's box (pt_box_robust: then every ancestor box passes the
+// reference's test whatever the rounding) and no second triangle was hit within a few ulp of it; the rare others are walked
+// again by the `exact` role with the reference's arithmetic on the unpadded boxes of the reference tree (ref_closest_hit,
+// ref_light_pdf_sum).  Pixels then match the reference's also where a ray grazes a box corner.
+#pragma once
+#include "rt_wavefront.h"
+
+namespace rtamd {
+namespace dev {
+
+#define PT_THREADS 1024
+#define PT_WAVES 16
+#define PT_MAX_PATHS 32768            // paths per workgroup (bitmap capacity in LDS)
+#define PT_NW (PT_MAX_PATHS / 32)
+#define PT_BIT_T 1u                   // pending: closest-hit walk outstanding
+#define PT_BIT_L 2u                   // pending: light-pdf sum outstanding
+#define PT_NONE 0xFFFFFFFFu
+// indices into PtShared::need / PtShared::cnt
+#define PT_Q_TRACE 0
+#define PT_Q_LIGHT 1
+#define PT_Q_SHADE 2
+#define PT_Q_XLIGHT 3                 // light sums for the exact walk (more than WF_MAX_LIGHT_HITS hits, or a hit at a box boundary)
+#define PT_Q_XTRACE 4                 // closest hits for the exact walk
+#define PT_N_LIVE 5                   // cnt only: pixels of this workgroup not finished yet
+#define PT_W_TRACE 6                  // cnt only: waves currently walking closest hits / light sums
+#define PT_W_LIGHT 7
+#define PT_SHADE_EXACT 4              // wf-style action code of pt_shade_item: the hit needs the exact walk before it is shaded
+
+struct PtShared {
+    uint32_t stack[PT_WAVES][WF_STACK][64];   // per-lane traversal stack columns, one area per wave
+    uint32_t need[5][PT_NW];
+    uint32_t pending[PT_NW * 2];              // 2 bits per path
+    int cnt[16];
+};
+
+struct PtParams {
+    uint32_t n_groups;                // 64-slot groups (8x8 sub-tiles) of this pass
+    int refill, leaf_batch;           // as in rt_wavefront.h (leaf_batch = batch | share << 16)
+    int shade_thr0, shade_thr_step;   // wave w stops refilling its walkers when need_shade holds >= thr0 + w * step paths
+    int cost_t, cost_l;               // relative cost of a closest-hit / light query (walker split)
+    unsigned long long deadline_ticks; // 100 MHz ticks a wave may spend in this launch before it gives up (error)
+    unsigned long long *counters;     // [0] closest-hit queries, [1] light queries, [2] node visits, [3] triangle tests, [10] discarded speculative hits, [12] exact closest hits, [13] exact light sums, [14] waves that gave up waiting (error)
+    unsigned long long *debug;        // nullable: per workgroup {start time, exit time of its last wave (100 MHz ticks), paths}
+};
+
+// wave-uniform state
+struct PtWave {
+    uint32_t nw, n_local, n_blocks, block;
+    uint32_t cur[5];
+    uint32_t rr;
+};
+
+RT_DEV uint32_t pt_slot(const PtWave &w, uint32_t l) { return (((l >> 6) * w.n_blocks + w.block) << 6) | (l & 63u); }
+RT_DEV int pt_count(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // a fresh LDS read each time
+
+// Claims one set bit per wanting lane.  Lane i looks at word (cursor + i) mod nw; inside a word the bits are served from a
+// rotating position, so no path waits behind a neighbour that is always ready.  Returns the local path index or PT_NONE.
+RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &cursor, uint32_t &rr, bool want) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t got = PT_NONE;
+    const uint32_t rot = rr & 31u;
+    rr += 7u;
+    for (uint32_t swept = 0; swept < nw; swept += 64u) {
+        const bool trying = want && got == PT_NONE;
+        if (!__ballot(trying)) break;
+        uint32_t w = cursor + lane, skip = 0;
+        if (nw >= 64u) { if (w >= nw) w -= nw; }
+        else { skip = lane / nw; w = w % nw; }          // several lanes per word: the k-th of them takes the k-th set bit
+        if (trying) {
+            const uint32_t v = bm[w];
+            uint32_t r = (v >> rot) | (v << ((32u - rot) & 31u));
+            for (uint32_t i = 0; i < skip && r; i++) r &= r - 1u;
+            if (r) {
+                const uint32_t b = ((uint32_t)__ffs((int)r) - 1u + rot) & 31u;
+                const uint32_t old = atomicAnd(&bm[w], ~(1u << b));
+                if (old & (1u << b)) got = w * 32u + b;
+            }
+        }
+        cursor += 64u;
+        if (cursor >= nw) cursor %= nw;
+    }
+    const unsigned long long m = __ballot(got != PT_NONE);
+    if (m && lane == 0) atomicSub(cnt, (int)__popcll(m));
+    return got;
+}
+
+// Sets the bit of path l in queue q for the lanes with `doit` (wave-uniform call).
+RT_DEV void pt_push(PtShared &sh, int q, uint32_t l, bool doit) {
+    if (doit) atomicOr(&sh.need[q][l >> 5], 1u << (l & 31u));
+    const unsigned long long m = __ballot(doit);
+    if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sh.cnt[q], (int)__popcll(m));
+}
+
+// One of the two walks of path l is done (its results are in HBM, ordered before this call by the caller's release fence):
+// clear its pending bit; whoever clears the last one hands the path to the shaders.  Wave-uniform call.
+RT_DEV void pt_complete(PtShared &sh, uint32_t l, uint32_t bit, bool doit) {
+    bool ready = false;
+    if (doit) {
+        const uint32_t shift = (l & 15u) * 2u;
+        const uint32_t old = atomicAnd(&sh.pending[l >> 4], ~(bit << shift));
+        ready = ((old >> shift) & 3u) == bit;
+    }
+    pt_push(sh, PT_Q_SHADE, l, ready);
+}
+
+// ---- reference-exact walks (the `exact` role) --------------------------------------------------------------------------
+// AABB::intersect -> intersectBoxAndRay(0.5 * (max - min), ray - 0.5 * (min + max), false), primitives.cpp:163-165,29-53.
+RT_DEV bool ref_box_test(F3 mn, F3 mx, F3 o, F3 d, float &t, bool &inside) {
+    const F3 s = 0.5f * (mx - mn);
+    const F3 oc = o - 0.5f * (mn + mx);
+    const F3 a = neg(s) - oc, b = s - oc;
+    const float a1x = a.x / d.x, a1y = a.y / d.y, a1z = a.z / d.z;
+    const float a2x = b.x / d.x, a2y = b.y / d.y, a2z = b.z / d.z;
+    const float t1x = smin(a1x, a2x), t2x = smax(a1x, a2x);
+    const float t1y = smin(a1y, a2y), t2y = smax(a1y, a2y);
+    const float t1z = smin(a1z, a2z), t2z = smax(a1z, a2z);
+    const float t1 = smax(smax(t1x, t1y), t1z);
+    const float t2 = smin(smin(t2x, t2y), t2z);
+    if (t1 > t2 || t2 < 0) return false;
+    if (t1 < 0) { inside = true; t = t2; }
+    else { inside = false; t = t1; }
+    return true;
+}
+
+struct RefNodeView { F3 mn, mx; uint32_t left, right, first, last; };
+RT_DEV RefNodeView load_ref_node(const GpuRefNode *p) {
+    const float4 *q = reinterpret_cast<const float4 *>(p);
+    const float4 a = q[0], b = q[1], c = q[2];
+    RefNodeView n;
+    n.mn = f3(a.x, a.y, a.z); n.left = __float_as_uint(a.w);
+    n.mx = f3(b.x, b.y, b.z); n.right = __float_as_uint(b.w);
+    n.first = __float_as_uint(c.x); n.last = __float_as_uint(c.y);
+    return n;
+}
+
+// BVH::intersect_ (bvh.h:111-142) as an iterative depth-first walk, left child first: the recursion's `curBest` is the running
+// best of all hits found so far, a leaf keeps its first triangle on equal t, and a later subtree replaces the best only when
+// strictly closer — so one running best with strict '<' reproduces the result.  `stack` holds up to RT_STACK_SIZE node indices.
+RT_DEV void ref_closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, float &best_t, float &best_u, float &best_v, uint32_t &hit) {
+    best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; hit = WF_MISS;
+    if (S.n_tris == 0) return;
+    int sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        const RefNodeView n = load_ref_node(S.ref_nodes + cur);
+        float tb; bool inside;
+        if (ref_box_test(n.mn, n.mx, o, d, tb, inside) && !(hit != WF_MISS && best_t < tb && !inside)) {
+            if (n.left == 0) {
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    const TriIsect T = load_isect(S.tri_isect + i);
+                    float t, u, v; bool in;
+                    if (tri_test(T, o, d, t, u, v, in) && (hit == WF_MISS || t < best_t)) {
+                        best_t = t; best_u = u; best_v = v; hit = i | (in ? WF_INSIDE_BIT : 0u);
+                    }
+                }
+            } else if (sp < RT_STACK_SIZE) { stack[sp++] = n.right; cur = n.left; continue; }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+
+// FiguresMix::getTotalPdf (distributions.h:148-165) over the reference light tree with the reference's box test and its
+// association of the additions (TODO / ADD frames as in light_pdf_sum, rt_device.h).
+RT_DEV float ref_light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack) {
+    int sp = 0;
+    unsigned long long addmask = 0;
+    uint32_t cur = 0;
+    bool descending = true;
+    float v = 0.f;
+    for (;;) {
+        if (descending) {
+            const RefNodeView n = load_ref_node(S.ref_light_nodes + cur);
+            float tb; bool inside;
+            if (!ref_box_test(n.mn, n.mx, x, d, tb, inside)) { v = 0.f; descending = false; }
+            else if (n.left == 0) {
+                float result = 0.f;
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    bool last;
+                    result += light_pdf_one(S.lights + i, x, d, last, S.hw7 != 0);
+                }
+                v = result;
+                descending = false;
+            } else if (sp < RT_STACK_SIZE) { addmask &= ~(1ull << sp); stack[sp++] = n.right; cur = n.left; }
+            else { v = 0.f; descending = false; } // deeper than the host admits (checked there)
+        } else {
+            if (sp == 0) break;
+            --sp;
+            const uint32_t f = stack[sp];
+            if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;                  // left total + right total
+            else { addmask |= 1ull << sp; stack[sp++] = __float_as_uint(v); cur = f; descending = true; }
+        }
+    }
+    return v;
+}
+
+// Is the point P = o + t d, hit on a triangle whose box is [lo, hi], robustly inside that box — so robustly that the reference's
+// slab test accepts this box and every box containing it whatever the rounding?  The reference computes per axis the slab
+// interval [ta_j, tb_j] in t (monotonic: never inverted on one axis) and accepts when max_j ta_j <= min_k tb_k and that
+// minimum is >= 0.  With a_j = t - ta_j, b_k = tb_k - t (exact, >= 0 for a point inside) the computed values are off by at
+// most ~2^-23 |t-ish| + 2^-24 |o - centre|_j / |d_j| each, so for every pair of different axes
+//     a_j + b_k >= c1 t + c2 (1/|d_j| + 1/|d_k|),   c1 = 2^-19,  c2 = 2^-20 max|coordinate|   (4x the bound)
+// is sufficient, and t + b_k >= c1 t keeps the exit in front of the origin.  Boxes only grow towards the root, which only
+// increases a_j and b_k.  A flat box (a_j = b_j = 0 on its axis) passes as long as the other axes have room.
+RT_DEV bool pt_box_robust(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
+    const float ix = 1.0f / fmaxf(fabsf(d.x), 1e-30f), iy = 1.0f / fmaxf(fabsf(d.y), 1e-30f), iz = 1.0f / fmaxf(fabsf(d.z), 1e-30f);
+    const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
+    const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
+    const float inz = d.z > 0 ? P.z - lo.z : hi.z - P.z, outz = d.z > 0 ? hi.z - P.z : P.z - lo.z;
+    const float ax = (inx - c2) * ix, ay = (iny - c2) * iy, az = (inz - c2) * iz;
+    const float bx = (outx - c2) * ix, by = (outy - c2) * iy, bz = (outz - c2) * iz;
+    const float need = 1.9073486328125e-06f * t;
+    const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
+    const float exit_ = t + fminf(fminf(bx, by), bz);
+    return worst >= need && exit_ >= need; // NaN compares false: not robust
+}
+
+// light_pdf_one (rt_device.h) that also says whether the hit is robust against the reference's box tests (pt_box_robust on
+// the light triangle's own box: a, a + b, a + c).
+RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d, bool &last, bool &robust) {
+    TriIsect T = load_isect(&L->isect);
+    last = T.pad != 0;
+    robust = true;
+    float t, u, v; bool inside;
+    if (!tri_test(T, x, d, t, u, v, inside)) return 0.f;
+    const float4 *q = reinterpret_cast<const float4 *>(L) + 3;
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    float point_prob = q1.z;
+    F3 n3 = f3(q1.w, q2.x, q2.y), dn1 = f3(q2.z, q2.w, q3.x), dn2 = f3(q3.y, q3.z, q3.w);
+    F3 sn = n3 + u * dn1 + v * dn2;           // primitives.cpp:110
+    sn = normalize(sn);                        // :117
+    if (inside) sn = neg(sn);                  // :118-119
+    if (S.hw7) { F3 n = f3(T.nx, T.ny, T.nz); sn = normalize(inside ? neg(n) : n); }
+    F3 y = x + t * d;                          // distributions.h:144
+    if (S.exact_boxes) {
+        const F3 a = f3(T.ax, T.ay, T.az), pb = a + f3(q0.x, q0.y, q0.z), pc = a + f3(q0.w, q1.x, q1.y);
+        const F3 lo = f3(fminf(a.x, fminf(pb.x, pc.x)), fminf(a.y, fminf(pb.y, pc.y)), fminf(a.z, fminf(pb.z, pc.z)));
+        const F3 hi = f3(fmaxf(a.x, fmaxf(pb.x, pc.x)), fmaxf(a.y, fmaxf(pb.y, pc.y)), fmaxf(a.z, fmaxf(pb.z, pc.z)));
+        robust = pt_box_robust(lo, hi, y, d, t, S.box_c2);
+    }
+    return point_prob * len2(x - y) / fabsf(dot(d, sn)); // :68-70 (pdfOne, shading normal in hw8)
+}
+
+// ---- closest-hit walker ------------------------------------------------------------------------------------------------
+// The traversal loop of rt_wavefront.h (while-while, near-first, tie -> lowest figure index) fed from the need_trace bitmap.
+// A finished lane keeps its path index in `fin` until the next refill point, where the wave orders its record stores before
+// the LDS hand-off with one workgroup-scope release.
+template <bool COUNT>
+RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
+                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
+    const int lane = threadIdx.x & 63;
+    bool active = false, tie = false, refill_ok = true;
+    uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
+    int sp = 0;
+    F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
+    RayInv ray = make_ray_inv(o, d);
+    float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
+    for (;;) {
+        if (__ballot(fin != PT_NONE)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
+            fin = PT_NONE;
+        }
+        const unsigned long long idle = __ballot(!active);
+        if (idle && refill_ok && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+            if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;      // shaders are behind: drain, then help them
+            else if (pt_count(&sh.cnt[PT_Q_TRACE]) > 0) {
+                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], wv.rr, !active);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                n_queries += __popcll(__ballot(got != PT_NONE));
+                if (got != PT_NONE) {
+                    l = got; slot = pt_slot(wv, l);
+                    const float4 *r = wf_rec(W, slot);
+                    float4 q0 = r[0], q1 = r[1];
+                    o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
+                    ray = make_ray_inv(o, d);
+                    cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; tie = false;
+                    active = true;
+                }
+            }
+        }
+        const unsigned long long m_active = __ballot(active);
+        if (!m_active) break;
+        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        for (;;) { // phase 1: inner nodes
+            const bool inner = active && !(cur & RT_LEAF_BIT);
+            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (inner) {
+                const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
+                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+                if (COUNT) n_nodes++;
+                float n0, n1;
+                bool h0 = slab_test(lo0, hi0, ray, best_t, n0);
+                bool h1 = slab_test(lo1, hi1, ray, best_t, n1);
+                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+                if (h0 & h1) {
+                    bool swap = n1 < n0;
+                    stack[sp++][lane] = swap ? c0 : c1;
+                    cur = swap ? c1 : c0;
+                } else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp == 0) {
+                    wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
+                    active = false; fin = l;
+                } else cur = stack[--sp][lane];
+            }
+        }
+        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    TriIsect T = load_isect(S.tri_isect + i);
+                    if (COUNT) n_tris++;
+                    float t, u, v; bool inside;
+                    if (tri_test(T, o, d, t, u, v, inside)) {
+                        // a second hit within the slab test's own tolerance of the best one: the reference's pruning may
+                        // order the two differently (bvh.h:118), so the exact walk decides
+                        const bool close = fabsf(t - best_t) <= 4.8e-7f * fmaxf(t, best_t);
+                        const uint32_t best_i = hit & WF_INDEX_MASK;
+                        if (t < best_t || (t == best_t && i < best_i)) {
+                            tie = close && hit != WF_MISS;
+                            best_t = t; best_u = u; best_v = v; hit = i | (inside ? WF_INSIDE_BIT : 0u);
+                        } else tie = tie || close;
+                    }
+                    if (T.pad) break;
+                    i++;
+                }
+            }
+            if (sp == 0) {
+                wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
+                active = false; fin = l;
+            } else cur = stack[--sp][lane];
+        }
+    }
+}
+
+// ---- light-sum walker (wf_light_loop_lean of rt_wavefront.h fed from the need_light bitmap) ----------------------------------
+template <bool COUNT>
+RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
+                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
+    const int lane = threadIdx.x & 63;
+    bool active = false, overflow = false, refill_ok = true;
+    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE;
+    int sp = 0, k = 0;
+    F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
+    RayInv ray = make_ray_inv(o, d);
+    auto finish = [&]() {
+        active = false;
+        if (overflow) { slow = l; return; }
+        float v = 0.f;
+        if (k == 1) v = __uint_as_float(stack[WF_STACK - 2][lane]);
+        else if (k == 2) v = __uint_as_float(stack[WF_STACK - 2][lane]) + __uint_as_float(stack[WF_STACK - 4][lane]);
+        else if (k > 2) { // the reference's association of the additions, see wf_light_loop_lean
+            const uint32_t nl = S.n_lights;
+            for (int j = 1; j < k; j++) {
+                uint32_t a0 = stack[WF_STACK - 1 - 2 * (j - 1)][lane], b0 = stack[WF_STACK - 1 - 2 * j][lane];
+                uint32_t len = b0 - a0;
+                uint32_t lv = 31u - (uint32_t)__clz((int)len);
+                uint16_t m0 = S.light_sep[(size_t)lv * nl + a0], m1 = S.light_sep[(size_t)lv * nl + (b0 - (1u << lv))];
+                stack[j - 1][lane] = m0 < m1 ? m0 : m1;
+            }
+            for (int n = k; n > 1; n--) {
+                int best = 1;
+                uint32_t bd = stack[0][lane];
+                for (int i = 2; i < n; i++) { uint32_t di = stack[i - 1][lane]; if (di > bd) { bd = di; best = i; } }
+                float merged = __uint_as_float(stack[WF_STACK - 2 - 2 * (best - 1)][lane]) + __uint_as_float(stack[WF_STACK - 2 - 2 * best][lane]);
+                stack[WF_STACK - 2 - 2 * (best - 1)][lane] = __float_as_uint(merged);
+                for (int i = best; i < n - 1; i++) {
+                    stack[WF_STACK - 2 - 2 * i][lane] = stack[WF_STACK - 2 - 2 * (i + 1)][lane];
+                    stack[i - 1][lane] = stack[i][lane];
+                }
+            }
+            v = __uint_as_float(stack[WF_STACK - 2][lane]);
+        }
+        int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
+        float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
+        *pdf = *pdf + v / (float)S.n_lights;                                  // distributions.h:123,273
+        fin = l;
+    };
+    for (;;) {
+        if (__ballot(fin != PT_NONE || slow != PT_NONE)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE);
+            pt_push(sh, PT_Q_XLIGHT, slow, slow != PT_NONE);
+            fin = PT_NONE; slow = PT_NONE;
+        }
+        const unsigned long long idle = __ballot(!active);
+        if (idle && refill_ok && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+            if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
+            else if (pt_count(&sh.cnt[PT_Q_LIGHT]) > 0) {
+                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], wv.rr, !active);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                n_queries += __popcll(__ballot(got != PT_NONE));
+                if (got != PT_NONE) {
+                    l = got; slot = pt_slot(wv, l);
+                    const float4 *r = wf_rec(W, slot);
+                    float4 q0 = r[0], q1 = r[1];
+                    o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
+                    ray = make_ray_inv(o, d);
+                    cur = 0; sp = 0; k = 0; overflow = false;
+                    active = true;
+                }
+            }
+        }
+        const unsigned long long m_active = __ballot(active);
+        if (!m_active) break;
+        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        for (;;) { // phase 1: inner nodes
+            const bool inner = active && !(cur & RT_LEAF_BIT);
+            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (inner) {
+                const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
+                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+                if (COUNT) n_nodes++;
+                float n0, n1;
+                bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
+                bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
+                else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp == 0) finish();
+                else cur = stack[--sp][lane];
+            }
+        }
+        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    bool last, robust;
+                    if (COUNT) n_tris++;
+                    float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust);
+                    if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
+                        if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= WF_STACK) overflow = true;
+                        else { stack[WF_STACK - 1 - 2 * k][lane] = i; stack[WF_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
+                    }
+                    if (last) break;
+                    i++;
+                }
+            }
+            if (sp == 0) finish();
+            else cur = stack[--sp][lane];
+        }
+    }
+}
+
+// ---- shader ------------------------------------------------------------------------------------------------------------
+// wf_shade_item behind the exactness gate: a hit that is not robust against the reference's box tests (or has a near tie)
+// and has not been through the exact walk yet goes there first (PT_SHADE_EXACT: nothing of the path's state is touched).
+RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, bool &discarded) {
+    if (S.exact_boxes) {
+        const float4 *r = wf_rec(W, slot);
+        const float4 q2 = r[2];
+        const uint32_t hit = __float_as_uint(q2.w);
+        const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
+        if (hit != WF_MISS && !(packed & WF_VERIFIED_BIT)) {
+            bool robust = !(hit & WF_NEAR_TIE_BIT);
+            if (robust) {
+                const float4 q0 = r[0], q1 = r[1];
+                const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+                const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
+                const float4 lo = bx[0], hi = bx[1];
+                robust = pt_box_robust(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), o + q2.x * d, d, q2.x, S.box_c2);
+            }
+            if (!robust) return PT_SHADE_EXACT;
+        }
+    }
+    return wf_shade_item(S, R, W, slot, nullptr, &discarded);
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, RenderView R, WfView W, PtParams P) {
+    __shared__ PtShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    PtWave wv;
+    wv.n_blocks = gridDim.x; wv.block = blockIdx.x;
+    const uint32_t n_local_groups = P.n_groups > wv.block ? (P.n_groups - wv.block + wv.n_blocks - 1u) / wv.n_blocks : 0u;
+    wv.n_local = n_local_groups * 64u;
+    wv.nw = n_local_groups * 2u;
+    if (wv.n_local == 0u) return;
+    if (P.debug && tid == 0) { P.debug[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); P.debug[3 * blockIdx.x + 2] = wv.n_local; }
+    for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
+    wv.rr = wave * 5u;
+
+    // ---- init: seed every pixel of this workgroup, first camera ray (wf_init_kernel of rt_wavefront.h) -----------------------
+    for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
+    for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
+    if (tid < 16u) sh.cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) {
+        const uint32_t l = base + tid;
+        bool started = false;
+        if (l < wv.n_local) {
+            const uint32_t slot = pt_slot(wv, l), gslot = slot + W.slot_base;
+            int x, y; bool inside; size_t out_index;
+            wf_slot_to_pixel(R, gslot, x, y, inside, out_index);
+            if (!inside) { // padding of a border tile in the compact shard layout
+                if (R.shard_count > 1 && (R.streams <= 1 || gslot < R.n_pixslots)) {
+                    if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
+                    if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
+                }
+            } else {
+                Rng rng;
+                rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (gslot / R.n_pixslots) * R.seed_stride : 0u)); // sceneio.cpp:389-391
+                F3 o, d;
+                wf_camera_ray(S, R, rng, x, y, o, d);
+                float4 *r = wf_rec(W, slot);
+                r[0] = make_float4(o.x, o.y, o.z, d.x);
+                r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
+                r[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                r[3] = make_float4(0.f, 0.f, 0.f, __uint_as_float(wf_pack(0, rng.has_saved, 0)));
+                atomicOr(&sh.pending[l >> 4], PT_BIT_T << ((l & 15u) * 2u));
+                started = true;
+            }
+        }
+        const unsigned long long m = __ballot(started);
+        if (m && lane == 0) atomicAdd(&sh.cnt[PT_N_LIVE], (int)__popcll(m));
+        pt_push(sh, PT_Q_TRACE, l, started);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ---- scheduler: every wave picks a role whenever it is idle ----------------------------------------------------------------
+    uint32_t(*stack)[64] = sh.stack[wave];
+    const int shade_thr = P.shade_thr0 + (int)wave * P.shade_thr_step;
+    unsigned long long n_closest = 0, n_light = 0, n_nodes = 0, n_tris = 0, n_xtrace = 0, n_xlight = 0, n_discarded = 0;
+    uint32_t idle_spins = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { // safety net: never hang the GPU; the host reports the error
+            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
+            break;
+        }
+        const int ns = pt_count(&sh.cnt[PT_Q_SHADE]), nt = pt_count(&sh.cnt[PT_Q_TRACE]), nl = pt_count(&sh.cnt[PT_Q_LIGHT]);
+        const int nx = pt_count(&sh.cnt[PT_Q_XLIGHT]) + pt_count(&sh.cnt[PT_Q_XTRACE]);
+        if (nx > 0) {
+            // exact role: one lane per query, the reference's own box arithmetic over the reference trees
+            uint32_t xstack[RT_STACK_SIZE];
+            uint32_t got = pt_pop(sh.need[PT_Q_XLIGHT], &sh.cnt[PT_Q_XLIGHT], wv.nw, wv.cur[PT_Q_XLIGHT], wv.rr, true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (got != PT_NONE) {
+                const uint32_t slot = pt_slot(wv, got);
+                const float4 *r = wf_rec(W, slot);
+                float4 q0 = r[0], q1 = r[1];
+                const F3 x = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+                float v;
+                if (S.exact_boxes) v = ref_light_pdf_sum(S, x, d, xstack);
+                else { Counters c; c.closest = c.lightq = c.nodes = c.tris = 0; v = light_pdf_sum<false>(S, x, d, xstack, c); }
+                int depth = (int)(__float_as_uint(r[3].w) & 15u);
+                float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
+                *pdf = *pdf + v / (float)S.n_lights;
+            }
+            n_xlight += __popcll(__ballot(got != PT_NONE));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
+            got = pt_pop(sh.need[PT_Q_XTRACE], &sh.cnt[PT_Q_XTRACE], wv.nw, wv.cur[PT_Q_XTRACE], wv.rr, true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (got != PT_NONE) {
+                const uint32_t slot = pt_slot(wv, got);
+                float4 *r = wf_rec(W, slot);
+                float4 q0 = r[0], q1 = r[1];
+                float bt, bu, bv; uint32_t hit;
+                ref_closest_hit(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, bt, bu, bv, hit);
+                r[2] = make_float4(bt, bu, bv, __uint_as_float(hit));
+                float *pk = reinterpret_cast<float *>(r + 3) + 3;
+                *pk = __uint_as_float(__float_as_uint(*pk) | WF_VERIFIED_BIT);
+            }
+            n_xtrace += __popcll(__ballot(got != PT_NONE));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
+            idle_spins = 0;
+            continue;
+        }
+        // shaders first when a full wave of paths waits (or when it is all there is to do)
+        if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
+            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], wv.rr, true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            int todo = 0;
+            bool discarded = false;
+            if (got != PT_NONE) todo = pt_shade_item(S, R, W, pt_slot(wv, got), discarded);
+            n_discarded += __popcll(__ballot(discarded));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const bool next = got != PT_NONE && (todo & WF_NEXT_TRACE), with_light = next && (todo & WF_NEXT_LIGHT);
+            if (next) atomicOr(&sh.pending[got >> 4], (PT_BIT_T | (with_light ? PT_BIT_L : 0u)) << ((got & 15u) * 2u));
+            pt_push(sh, PT_Q_TRACE, got, next);
+            pt_push(sh, PT_Q_LIGHT, got, with_light);
+            pt_push(sh, PT_Q_XTRACE, got, got != PT_NONE && todo == PT_SHADE_EXACT);
+            const unsigned long long done = __ballot(got != PT_NONE && todo == 0);
+            if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
+            idle_spins = 0;
+            continue;
+        }
+        if (nt + nl > 0) {
+            // walkers: the kind whose backlog per walking wave (weighted by the cost of a query) is larger
+            const long long wt = (long long)nt * P.cost_t * (pt_count(&sh.cnt[PT_W_LIGHT]) + 1), wl = (long long)nl * P.cost_l * (pt_count(&sh.cnt[PT_W_TRACE]) + 1);
+            if (nl == 0 || (nt > 0 && wt >= wl)) {
+                if (lane == 0) atomicAdd(&sh.cnt[PT_W_TRACE], 1);
+                pt_trace_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_closest, n_nodes, n_tris);
+                if (lane == 0) atomicSub(&sh.cnt[PT_W_TRACE], 1);
+            } else {
+                if (lane == 0) atomicAdd(&sh.cnt[PT_W_LIGHT], 1);
+                pt_light_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_light, n_nodes, n_tris);
+                if (lane == 0) atomicSub(&sh.cnt[PT_W_LIGHT], 1);
+            }
+            idle_spins = 0;
+            continue;
+        }
+        if (pt_count(&sh.cnt[PT_N_LIVE]) <= 0) break;
+        // paths are in flight in other waves' registers: wait for them
+        __builtin_amdgcn_s_sleep(8);
+        if (++idle_spins > (1u << 24)) { // safety net (seconds): never hang the GPU on a lost path; the host reports it
+            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
+            break;
+        }
+    }
+    if (lane == 0 && P.counters) {
+        if (n_closest) atomicAdd(&P.counters[0], n_closest);
+        if (n_light) atomicAdd(&P.counters[1], n_light);
+        if (n_discarded) atomicAdd(&P.counters[10], n_discarded);
+        if (n_xtrace) atomicAdd(&P.counters[12], n_xtrace);
+        if (n_xlight) atomicAdd(&P.counters[13], n_xlight);
+    }
+    if (COUNT && P.counters) { atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris); }
+    if (P.debug && lane == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&P.debug[3 * blockIdx.x + 1], now);
+    }
+}
+
+} // namespace dev
+} // namespace rtamd

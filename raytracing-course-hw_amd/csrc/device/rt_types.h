@@ -53,6 +53,15 @@ struct LightRec {
 };
 static_assert(sizeof(LightRec) == 48 + 64, "LightRec must be 112 bytes");
 
+// Node of the reference's own tree with its UNPADDED box (hw8/src/include/bvh.h:9-16), for the reference-exact walks of
+// rt_persistent.h: left == 0 marks a leaf holding the figures (lights) [first, last) of the reference order.
+struct GpuRefNode {
+    float mn[3]; uint32_t left;
+    float mx[3]; uint32_t right;
+    uint32_t first, last, pad0, pad1;
+};
+static_assert(sizeof(GpuRefNode) == 48, "GpuRefNode must be 48 bytes");
+
 struct GpuMaterial {
     float base_color[3]; float metallic_factor;
     float emission[3];   float roughness_factor;
@@ -77,6 +86,12 @@ struct SceneView {
     const GpuImage *images;
     const uint8_t *texels;
     const float *srgb_lut;         // 256 entries: powf(float(1/255.)*b, 2.2f) evaluated by the host libm
+    // reference-exact box decisions (rt_persistent.h): the reference's trees with unpadded boxes, per figure its own box
+    // (min, max — primitives.cpp:130-141), and the robustness margin c2 = 2^-20 * max |coordinate| of scene and camera
+    const GpuRefNode *ref_nodes, *ref_light_nodes;
+    const float *tri_box;          // 8 floats per figure: min.xyz, 0, max.xyz, 0
+    float box_c2;
+    uint32_t exact_boxes;          // 0 = accept every hit of the conservative walk (the round pipeline's behaviour)
     uint32_t n_tris, n_lights, n_components;
     // 1 when every material has 0 <= metallicFactor <= 1 and a non-negative base colour: then the BRDF is >= 0,
     // the throughput of the deepest level is in [0, inf] or NaN, and that level returns exactly its emission

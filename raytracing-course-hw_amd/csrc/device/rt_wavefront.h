@@ -55,6 +55,10 @@ RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0
 
 #define WF_MISS 0xFFFFFFFFu
 #define WF_INSIDE_BIT 0x40000000u
+#define WF_NEAR_TIE_BIT 0x80000000u   // persistent pipeline: another triangle was hit within a few ulp of the best t (never set on WF_MISS)
+#define WF_INDEX_MASK 0x3FFFFFFFu
+#define WF_SAMPLE_MASK 0x01FFFFFFu    // 25 bits of sample index in the packed word
+#define WF_VERIFIED_BIT 0x80000000u   // packed word: the hit in q2 comes from the reference-exact walk
 #define WF_CTR 8               // counter words per round
 #ifndef WF_STACK
 #define WF_STACK 30            // LDS traversal stack entries per lane: 30 KB per block, so that five blocks are resident per CU
@@ -111,28 +115,31 @@ RT_DEV void wf_camera_ray(const SceneView &S, const RenderView &R, Rng &rng, int
 }
 
 // End of one camera sample: fold e + m*(inner) backwards (scene.cpp:164), add to the pixel sum
-// (scene.cpp:174), then either start the next sample or write the finished pixel.
-RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, int depth, F3 tail, F3 accum,
-                           Rng &rng, uint32_t sample, const Pusher &next) {
+// (scene.cpp:174), then either start the next sample (returns true: the slot holds a new camera ray that wants tracing)
+// or write the finished pixel (returns false).  The pixel sum is read here, not carried through the shading code.
+RT_DEV bool wf_finish_path(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, int depth, F3 tail,
+                           Rng &rng, uint32_t sample) {
     F3 L = tail;
     for (int b = depth - 1; b >= 0; b--) {
         const float4 *e = wf_entry(W, slot, b);
         float4 e0 = e[0], e1 = e[1];
         L = f3(e0.x, e0.y, e0.z) + f3(e1.x, e1.y, e1.z) * L;
     }
-    accum = accum + L;
+    float4 *r = wf_rec(W, slot);
+    float4 q3 = r[3];
+    F3 accum = f3(q3.x, q3.y, q3.z) + L;
     sample++;
     int x, y; bool inside; size_t out_index;
     wf_slot_to_pixel(R, slot + W.slot_base, x, y, inside, out_index);
     if (sample < (uint32_t)R.samples) {
         F3 o, d;
         wf_camera_ray(S, R, rng, x, y, o, d);
-        float4 *r = wf_rec(W, slot);
         r[0] = make_float4(o.x, o.y, o.z, d.x);
         r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
         r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(0, rng.has_saved, sample)));
-        wf_push(next, slot);
-    } else if (R.streams > 1) {                                      // throughput mode: this stream's unnormalised sum
+        return true;
+    }
+    if (R.streams > 1) {                                             // throughput mode: this stream's unnormalised sum
         float *o = R.partial + 3 * (size_t)(slot + W.slot_base);
         o[0] = accum.x; o[1] = accum.y; o[2] = accum.z;
     } else {
@@ -142,6 +149,7 @@ RT_DEV void wf_finish_path(const SceneView &S, const RenderView &R, const WfView
             R.out_rgb8[3 * out_index] = tonemap1(px.x); R.out_rgb8[3 * out_index + 1] = tonemap1(px.y); R.out_rgb8[3 * out_index + 2] = tonemap1(px.z);
         }
     }
+    return false;
 }
 
 // ---- init: seed every pixel, first camera ray, fill the round-0 trace queue ------------------------------
@@ -597,22 +605,28 @@ __global__ __launch_bounds__(64) void wf_light_exact_kernel(SceneView S, WfView 
 }
 
 // ---- shade: finish the pending bounce (scene.cpp:158-164), then scene.cpp:89-156 for the new hit ------------------------
-RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, const Pusher &to_light, const Pusher &next,
-                          unsigned long long *counters) {
+// Returns what the slot needs next: WF_NEXT_TRACE (its record holds a ray to trace: a new bounce or the next sample's camera
+// ray), | WF_NEXT_LIGHT (that ray is also a bounce's light-pdf query), or 0 (the pixel is finished and written).
+#define WF_NEXT_TRACE 1
+#define WF_NEXT_LIGHT 2
+RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, unsigned long long *counters, bool *discarded = nullptr) {
     float4 *r = wf_rec(W, slot);
-    float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-    F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+    float4 q0 = r[0], q1 = r[1], q2 = r[2];
+    F3 d = f3(q0.w, q1.x, q1.y);
     Rng rng; rng.x = __float_as_uint(q1.z); rng.saved = q1.w;
-    uint32_t packed = __float_as_uint(q3.w);
+    const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
     int depth = (int)(packed & 15u);
     rng.has_saved = (packed & 16u) != 0;
-    uint32_t sample = packed >> 6;
-    F3 accum = f3(q3.x, q3.y, q3.z);
+    const uint32_t sample = (packed >> 6) & WF_SAMPLE_MASK;
+    // A path that ends here (miss, clamp, early-out, deepest level) returns `tail` from its innermost call below `levels` bounces.
+    bool ended = false;
+    F3 tail = f3(0.f, 0.f, 0.f);
+    int levels = 0;
     if (packed & WF_PENDING_BIT) {
         // The bounce at `depth` sampled the ray that was just traced; its pdf is complete now (Mix::pdf, distributions.h:268-278).
         float4 *e = wf_entry(W, slot, depth);
         float4 e0 = e[0], e1 = e[1];
-        F3 emission = f3(e0.x, e0.y, e0.z), brdf = f3(e1.x, e1.y, e1.z);
+        F3 brdf = f3(e1.x, e1.y, e1.z);
         float pdf = e0.w / (float)S.n_components;                              // :278
         float k = (float)(1. / (double)pdf * fabs((double)e1.w));              // scene.cpp:159
         F3 mult = k * brdf;
@@ -621,58 +635,64 @@ RT_DEV void wf_shade_item(const SceneView &S, const RenderView &R, const WfView 
             // clamp hack (scene.cpp:161-163): the path returns the emission and the speculative hit is dropped; at the
             // last level the inner call returns 0, i.e. emission + mult * 0 evaluated literally.
             if (counters) atomicAdd(&counters[10], 1ull);
-            F3 tail = emission;
-            int levels = depth;
+            if (discarded) *discarded = true;
+            ended = true;
+            tail = f3(e0.x, e0.y, e0.z);
+            levels = depth;
             if (!clamp) { e[1] = make_float4(mult.x, mult.y, mult.z, e1.w); tail = f3(0.f, 0.f, 0.f); levels = depth + 1; }
-            wf_finish_path(S, R, W, slot, levels, tail, accum, rng, sample, next);
-            return;
+        } else {
+            e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
+            depth++;
         }
-        e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
-        depth++;
     }
-    uint32_t hit = __float_as_uint(q2.w);
-    if (hit == WF_MISS) { wf_finish_path(S, R, W, slot, depth, miss_color(S, d), accum, rng, sample, next); return; }
-    HitRec h;
-    h.idx = (int)(hit & ~WF_INSIDE_BIT); h.inside = (hit & WF_INSIDE_BIT) != 0; h.t = q2.x; h.u = q2.y; h.v = q2.z;
-    if (S.last_level_emission_only && depth + 1 >= R.ray_depth) {
-        // Deepest level: whatever Mix::sample / brdf / pdf produce, getColor returns its emission (see
-        // SceneView::last_level_emission_only).  Only the random draws must still happen, in order
-        // (distributions.h:257, then 3 normals | u1,u2 | index,u,v).
-        F3 emission = emission_fetch(S, h);
-        int comp = (int)(rng_u01(rng) * (float)S.n_components);
-        if (comp == 0) { rng_n01(rng); rng_n01(rng); rng_n01(rng); }
-        else if (comp == 2) { rng_u01(rng); rng_u01(rng); rng_u01(rng); }
-        else { rng_u01(rng); rng_u01(rng); }
-        wf_finish_path(S, R, W, slot, depth, emission, accum, rng, sample, next);
-        return;
+    if (!ended) {
+        const uint32_t hit = __float_as_uint(q2.w);
+        levels = depth;
+        if (hit == WF_MISS) { ended = true; tail = miss_color(S, d); }
+        else {
+            HitRec h;
+            h.idx = (int)(hit & WF_INDEX_MASK); h.inside = (hit & WF_INSIDE_BIT) != 0; h.t = q2.x; h.u = q2.y; h.v = q2.z;
+            if (S.last_level_emission_only && depth + 1 >= R.ray_depth) {
+                // Deepest level: whatever Mix::sample / brdf / pdf produce, getColor returns its emission (see
+                // SceneView::last_level_emission_only).  Only the random draws must still happen, in order
+                // (distributions.h:257, then 3 normals | u1,u2 | index,u,v).
+                tail = emission_fetch(S, h);
+                int comp = (int)(rng_u01(rng) * (float)S.n_components);
+                if (comp == 0) { rng_n01(rng); rng_n01(rng); rng_n01(rng); }
+                else if (comp == 2) { rng_u01(rng); rng_u01(rng); rng_u01(rng); }
+                else { rng_u01(rng); rng_u01(rng); }
+                ended = true;
+            } else {
+                F3 ng, base_color; float base_metallic; Shaded sh;
+                shade_fetch(S, h, ng, sh, base_color, base_metallic);
+                F3 x = f3(q0.x, q0.y, q0.z) + h.t * d;                                 // scene.cpp:104
+                F3 xo = x + 9.99999974737875163555e-05f * ng;                          // x + eps * geomNorma
+                int comp = (int)(rng_u01(rng) * (float)S.n_components);               // distributions.h:257
+                F3 nd;
+                if (comp == 0) nd = cosine_sample(rng, sh.sn);
+                else if (comp == 2) nd = light_sample(S, rng, xo);
+                else nd = vndf_sample(rng, sh.sn, d, sh.alpha);
+                F3 brdf = S.hw7 ? material_brdf_hw7(base_color, base_metallic, nd, neg(d), sh.sn, sh.alpha * sh.alpha)
+                                : material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha);
+                const float epsf = 9.99999974737875163555e-05f;
+                if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) {             // scene.cpp:154-156
+                    ended = true; tail = sh.emission;
+                } else {
+                    float pdf = 0.f;                                                   // distributions.h:268-276, first two terms
+                    pdf += cosine_pdf(sh.sn, nd);
+                    pdf += vndf_pdf(sh.sn, nd, d, sh.alpha);
+                    float4 *e = wf_entry(W, slot, depth);
+                    e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, pdf);
+                    e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sh.sn));
+                    r[0] = make_float4(xo.x, xo.y, xo.z, nd.x);                       // the next ray doubles as the light query
+                    r[1] = make_float4(nd.y, nd.z, __uint_as_float(rng.x), rng.saved);
+                    reinterpret_cast<float *>(r + 3)[3] = __uint_as_float(wf_pack(depth, rng.has_saved, sample, true));
+                    return WF_NEXT_TRACE | (S.n_lights ? WF_NEXT_LIGHT : 0);           // traced speculatively beside its own light-pdf sum
+                }
+            }
+        }
     }
-    F3 ng, base_color; float base_metallic; Shaded sh;
-    shade_fetch(S, h, ng, sh, base_color, base_metallic);
-    F3 x = o + h.t * d;                                                    // scene.cpp:104
-    F3 xo = x + 9.99999974737875163555e-05f * ng;                          // x + eps * geomNorma
-    int comp = (int)(rng_u01(rng) * (float)S.n_components);               // distributions.h:257
-    F3 nd;
-    if (comp == 0) nd = cosine_sample(rng, sh.sn);
-    else if (comp == 2) nd = light_sample(S, rng, xo);
-    else nd = vndf_sample(rng, sh.sn, d, sh.alpha);
-    F3 brdf = S.hw7 ? material_brdf_hw7(base_color, base_metallic, nd, neg(d), sh.sn, sh.alpha * sh.alpha)
-                    : material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha);
-    const float epsf = 9.99999974737875163555e-05f;
-    if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) {             // scene.cpp:154-156
-        wf_finish_path(S, R, W, slot, depth, sh.emission, accum, rng, sample, next);
-        return;
-    }
-    float pdf = 0.f;                                                       // distributions.h:268-276, first two terms
-    pdf += cosine_pdf(sh.sn, nd);
-    pdf += vndf_pdf(sh.sn, nd, d, sh.alpha);
-    float4 *e = wf_entry(W, slot, depth);
-    e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, pdf);
-    e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sh.sn));
-    r[0] = make_float4(xo.x, xo.y, xo.z, nd.x);                           // the next ray doubles as the light query
-    r[1] = make_float4(nd.y, nd.z, __uint_as_float(rng.x), rng.saved);
-    r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(depth, rng.has_saved, sample, true)));
-    wf_push(next, slot);                                                   // traced speculatively next round ...
-    if (S.n_lights) wf_push(to_light, slot);                               // ... beside its own light-pdf sum
+    return wf_finish_path(S, R, W, slot, levels, tail, rng, sample) ? WF_NEXT_TRACE : 0;
 }
 
 // Throughput mode epilogue: pixel = float(1/spp) * (sum of its K stream sums, added in stream order), then the usual tonemap.
@@ -707,7 +727,12 @@ __global__ __launch_bounds__(256, WF_SHADE_OCC) void wf_shade_kernel(SceneView S
     uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + WF_CTR * (round + 1) + 0, *light_count = W.ctr + WF_CTR * (round + 1) + 1;
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t i = base + threadIdx.x;
-        if (i < count) wf_shade_item(S, R, W, queue[i], to_light, next, counters);
+        if (i < count) {
+            const uint32_t slot = queue[i];
+            const int todo = wf_shade_item(S, R, W, slot, counters);
+            if (todo & WF_NEXT_TRACE) wf_push(next, slot);
+            if (todo & WF_NEXT_LIGHT) wf_push(to_light, slot);
+        }
         __syncthreads();
         if (cnt_l > WF_BUF - 256) wf_flush(to_light, W.q_light, light_count, &gbase);
         if (cnt_n > WF_BUF - 256) wf_flush(next, next_queue, next_count, &gbase);

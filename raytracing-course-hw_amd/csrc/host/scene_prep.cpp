@@ -192,6 +192,18 @@ void encode_tree(const std::vector<RefNode> &ref, std::vector<GpuNode> &out, std
     }
 }
 
+// The reference tree as the exact walks read it (unpadded boxes, preorder numbering of the builder).
+void encode_ref_tree(const std::vector<RefNode> &ref, std::vector<GpuRefNode> &out) {
+    out.resize(ref.empty() ? 1 : ref.size());
+    if (ref.empty()) { memset(&out[0], 0, sizeof out[0]); return; }
+    for (size_t i = 0; i < ref.size(); i++) {
+        GpuRefNode &g = out[i];
+        for (int k = 0; k < 3; k++) { g.mn[k] = ref[i].box.lo[k]; g.mx[k] = ref[i].box.hi[k]; }
+        g.left = ref[i].left; g.right = ref[i].right; g.first = ref[i].first; g.last = ref[i].last;
+        g.pad0 = g.pad1 = 0;
+    }
+}
+
 struct V3 { float x, y, z; };
 inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 crossr(V3 a, V3 o) { return {a.z * o.y - a.y * o.z, a.x * o.z - a.z * o.x, a.y * o.x - a.x * o.y}; } // vec3.h:57-59
@@ -241,9 +253,10 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     RefBuilder scene_builder(keys, boxes, out.figure_order);
     scene_builder.run(n);
     out.bvh_depth = scene_builder.depth;
-    out.ref_nodes = (uint32_t)scene_builder.nodes.size();
+    out.n_ref_nodes = (uint32_t)scene_builder.nodes.size();
     std::vector<uint32_t> scene_leaf_last, light_leaf_last;
     encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
+    encode_ref_tree(scene_builder.nodes, out.ref_nodes);
 
     // ---- 2. light order ---------------------------------------------------------------------------
     auto emissive = [&](uint32_t tri) { // distributions.h:104-109: the FACTOR decides, not the texture
@@ -256,6 +269,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     light_builder.run(n_lights);
     out.light_bvh_depth = light_builder.depth;
     encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    encode_ref_tree(light_builder.nodes, out.ref_light_nodes);
     { // separation depths of neighbouring lights + sparse table for range minima (see scene_prep.h)
         const std::vector<RefNode> &rn = light_builder.nodes;
         const uint32_t nl = n_lights;
@@ -294,8 +308,16 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     // ---- 3. records ---------------------------------------------------------------------------------
     out.isect.resize(n);
     out.shade.resize(n);
+    out.tri_box.assign((size_t)(n ? n : 1) * 8, 0.f);
+    float max_coord = 0.f;
+    for (int k = 0; k < 3; k++) max_coord = smax(max_coord, std::fabs(d.camera.position[k]));
     for (uint32_t i = 0; i < n; i++) {
         uint32_t src = out.figure_order[i];
+        for (int k = 0; k < 3; k++) {
+            out.tri_box[8 * (size_t)i + k] = boxes[src].lo[k];
+            out.tri_box[8 * (size_t)i + 4 + k] = boxes[src].hi[k];
+            max_coord = smax(max_coord, smax(std::fabs(boxes[src].lo[k]), std::fabs(boxes[src].hi[k])));
+        }
         out.isect[i] = make_isect(d.positions + 9 * (size_t)src);
         TriShade &s = out.shade[i];
         memset(&s, 0, sizeof s);
@@ -315,6 +337,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
         s.material = d.material_index[src];
         s.orig = src;
     }
+    out.box_c2 = max_coord * 9.5367431640625e-07f; // 2^-20
     for (uint32_t i : scene_leaf_last) out.isect[i].pad = 1;
     out.lights.resize(n_lights);
     for (uint32_t i = 0; i < n_lights; i++) {

@@ -10,6 +10,11 @@ namespace rtamd {
 
 struct PreparedScene {
     std::vector<GpuNode> nodes, light_nodes;
+    // The reference's own trees with their unpadded boxes, and every figure's own box (BVH order): what the reference-exact
+    // walks of the persistent pipeline read (device/rt_persistent.h); box_c2 = 2^-20 * the largest |coordinate| of scene and camera.
+    std::vector<GpuRefNode> ref_nodes, ref_light_nodes;
+    std::vector<float> tri_box;
+    float box_c2 = 0.f;
     // Order of the light-pdf additions without walking the reference tree: light_sep[j * n_lights + i] = the shallowest
     // separation depth among the boundaries i .. i + 2^j - 1 (boundary b lies between lights b and b+1 of the reference order;
     // its depth is that of the reference-tree node whose children hold the two lights, or, inside one leaf, a pseudo depth
@@ -26,7 +31,7 @@ struct PreparedScene {
     int32_t env_image = -1;
     std::vector<uint32_t> figure_order; // BVH order -> LOAD index
     std::vector<uint32_t> light_order;  // light order -> LOAD index
-    uint32_t bvh_depth = 0, light_bvh_depth = 0, ref_nodes = 0;
+    uint32_t bvh_depth = 0, light_bvh_depth = 0, n_ref_nodes = 0;
 };
 
 // Throws std::runtime_error on invalid input.

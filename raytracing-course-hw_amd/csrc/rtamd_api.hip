@@ -16,6 +16,7 @@
 #include "host/scene_prep.h"
 #include "device/rt_kernels_hw8.h"
 #include "device/rt_wavefront.h"
+#include "device/rt_persistent.h"
 #include "device/rt_kernels_hw6.h"
 #include "device/rt_kernels_txt.h"
 #include "device/rt_kernels_hw2.h"
@@ -59,6 +60,12 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Device buffer owned by one rt_render call (host-output renders): freed on every way out of the call.
+struct OwnedDev {
+    void *p = nullptr;
+    ~OwnedDev() { if (p) (void)hipFree(p); }
+};
+
 int fail(int code, const std::string &msg) {
     set_error(msg);
     return code;
@@ -94,6 +101,11 @@ struct rt_scene {
     float *d_partial = nullptr;      // throughput mode: per-stream pixel sums
     size_t partial_bytes = 0;
     std::vector<hipEvent_t> ev_pool; // brackets every launch of the dominant kernel when stats are requested
+    unsigned long long *d_pt_debug = nullptr; // persistent pipeline: per workgroup {start, exit time, paths} (RTAMD_DEBUG_COUNTERS)
+    float4 *pt_r0 = nullptr;         // persistent pipeline: path records of one pass
+    size_t pt_slots = 0, pt_levels = 0;
+    uint32_t pt_passes = 0, pt_blocks = 0;
+    int pipeline = 0;                // RT_PIPELINE_* of the last render
     void free_wf() {
         for (void *p : wf_allocs) (void)hipFree(p);
         wf_allocs.clear();
@@ -103,6 +115,8 @@ struct rt_scene {
     ~rt_scene() {
         free_wf();
         if (d_partial) (void)hipFree(d_partial);
+        if (pt_r0) (void)hipFree(pt_r0);
+        if (d_pt_debug) (void)hipFree(d_pt_debug);
         for (void *p : allocations) (void)hipFree(p);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
@@ -267,6 +281,11 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         V.tri_shade = keep(upload(P.shade, bytes));
         V.light_nodes = keep(upload(P.light_nodes, bytes));
         V.light_sep = keep(upload(P.light_sep, bytes));
+        V.ref_nodes = keep(upload(P.ref_nodes, bytes));
+        V.ref_light_nodes = keep(upload(P.ref_light_nodes, bytes));
+        V.tri_box = keep(upload(P.tri_box, bytes));
+        V.box_c2 = P.box_c2;
+        V.exact_boxes = getenv("RTAMD_NO_EXACT_BOXES") ? 0u : 1u;
         V.lights = keep(upload(P.lights, bytes));
         V.materials = keep(upload(P.materials, bytes));
         V.images = keep(upload(P.images, bytes));
@@ -517,6 +536,62 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
         }
 }
 
+// Persistent dataflow driver (device/rt_persistent.h): ONE launch renders up to n_cus x PT_MAX_PATHS path slots; larger frames
+// (or throughput mode with many streams) take several passes over disjoint slot ranges, each a complete render of its pixels.
+// Every launch is bracketed by events when `time_trace` (ev_pool[2p], ev_pool[2p+1]).
+static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
+    auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
+    uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus); // one 1024-thread workgroup per CU (its LDS fills the CU)
+    const uint32_t groups_per_block = PT_MAX_PATHS / 64;
+    const uint64_t pass_cap = (uint64_t)n_blocks_max * groups_per_block;
+    const uint32_t passes = (uint32_t)((n_work + pass_cap - 1) / pass_cap);
+    const uint32_t pass_groups = (n_work + passes - 1) / passes;
+    const size_t n_slots = (size_t)pass_groups * 64;
+    if (scene->pt_slots < n_slots || scene->pt_levels < (size_t)R.ray_depth) {
+        if (scene->pt_r0) (void)hipFree(scene->pt_r0);
+        scene->pt_r0 = nullptr; scene->pt_slots = scene->pt_levels = 0;
+        HIP_CHECK(hipMalloc((void **)&scene->pt_r0, n_slots * (64 + 32 * (size_t)R.ray_depth)));
+        scene->pt_slots = n_slots; scene->pt_levels = (size_t)R.ray_depth;
+    }
+    dev::PtParams P{};
+    const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
+    P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL);
+    P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 64);
+    P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 128);
+    P.cost_t = 7; P.cost_l = 8;
+    if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) { P.cost_t = a; P.cost_l = b; } }
+    P.counters = scene->d_counters;
+    P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
+    P.debug = nullptr;
+    if (getenv("RTAMD_DEBUG_COUNTERS")) {
+        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)1024 * 3 * sizeof(unsigned long long)));
+        HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
+        if (n_blocks_max <= 1024) P.debug = scene->d_pt_debug;
+    }
+    if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
+    dev::WfView W{};
+    W.r0 = scene->pt_r0;
+    W.stride = 4u + 2u * (uint32_t)scene->pt_levels;
+    uint32_t first = 0;
+    scene->pt_blocks = 0;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t groups = n_work - first < pass_groups ? n_work - first : pass_groups;
+        W.n_slots = groups * 64u;
+        W.slot_base = first * 64u;
+        P.n_groups = groups;
+        const uint32_t blocks = groups < n_blocks_max ? groups : n_blocks_max;
+        if (blocks > scene->pt_blocks) scene->pt_blocks = blocks;
+        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * p], stream));
+        if (count) hipLaunchKernelGGL(dev::pt_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, R, W, P);
+        else hipLaunchKernelGGL(dev::pt_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, R, W, P);
+        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * p + 1], stream));
+        first += groups;
+    }
+    HIP_CHECK(hipGetLastError());
+    scene->pt_passes = passes;
+}
+
 int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
     if (!scene || !p) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID_ARG, "rt_render: struct_size mismatch (ABI skew)");
@@ -536,6 +611,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
     float *d_rgb = nullptr;
     uint8_t *d_rgb8 = nullptr;
     bool own_rgb = false, own_rgb8 = false;
+    OwnedDev rgb_buf, rgb8_buf;
     try {
         HIP_CHECK(hipSetDevice(scene->device));
         hipStream_t stream = (hipStream_t)p->stream;
@@ -544,11 +620,11 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         size_t elems = rt_output_elems(p);
         if (out_rgb) {
             if (out_dev) d_rgb = out_rgb;
-            else { HIP_CHECK(hipMalloc((void **)&d_rgb, elems * sizeof(float))); own_rgb = true; }
+            else { HIP_CHECK(hipMalloc(&rgb_buf.p, elems * sizeof(float))); d_rgb = (float *)rgb_buf.p; own_rgb = true; }
         }
         if (out_rgb8) {
             if (out_dev) d_rgb8 = out_rgb8;
-            else { HIP_CHECK(hipMalloc((void **)&d_rgb8, elems)); own_rgb8 = true; }
+            else { HIP_CHECK(hipMalloc(&rgb8_buf.p, elems)); d_rgb8 = (uint8_t *)rgb8_buf.p; own_rgb8 = true; }
         }
         R.out_rgb = d_rgb; R.out_rgb8 = d_rgb8;
         R.work_counter = scene->d_work_counter;
@@ -566,8 +642,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             if ((uint64_t)n_work * 64u * (uint64_t)streams >= 0x40000000ull) return fail(RT_ERR_LIMIT, "rt_render: too many path slots (pixels of this shard x sample_streams)");
         }
         HIP_CHECK(hipMemsetAsync(scene->d_work_counter, 0, 4, stream));
+        HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 512, stream));
         if (count) {
-            HIP_CHECK(hipMemsetAsync(scene->d_counters, 0, 512, stream));
             if (getenv("RTAMD_DEBUG_COUNTERS")) HIP_CHECK(hipMemsetAsync(scene->d_counters + 15, 1, 1, stream)); // asks the counting kernels for the in-flight histograms
         }
         uint32_t blocks = (uint32_t)scene->n_cus * 16u;
@@ -578,7 +654,10 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         bool use_wavefront = !(ksel && strcmp(ksel, "mega") == 0);
         if (scene->info.bvh_depth > WF_STACK + WF_OVF || scene->info.light_bvh_depth > 64 || scene->info.n_triangles >= 0x40000000u) use_wavefront = false; // light depth: 64-bit frame mask
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
-        if (R.samples / streams >= (1 << 26)) use_wavefront = false; // the path record keeps the sample index in 26 bits
+        if (R.samples / streams >= (1 << 25)) use_wavefront = false; // the path record keeps the sample index in 25 bits
+        // persistent dataflow pipeline (default) | round pipeline (RTAMD_KERNEL=wavefront, and for trees deeper than the LDS stack columns)
+        bool use_persistent = use_wavefront && !(ksel && strcmp(ksel, "wavefront") == 0) &&
+                              scene->info.bvh_depth <= WF_STACK && scene->info.light_bvh_depth <= WF_STACK && !getenv("RTAMD_WF_LDS_STACK");
         if (streams > 1 && !use_wavefront) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 needs the wavefront kernels (RTAMD_KERNEL=mega or a tree beyond their limits is in effect)");
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
         if (txt_scene && scene->txt_has_triangles && p->integrator != RT_INTEGRATOR_HW5) return fail(RT_ERR_INVALID_ARG, "rt_render: a .txt scene with TRIANGLE figures renders with RT_INTEGRATOR_HW5 only");
@@ -611,9 +690,15 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                     R.partial = scene->d_partial;
                 }
                 // every traverse launch is bracketed by events when stats are wanted -- up to 64 k rounds (e.g. 10,922 spp at depth 6)
+                if (use_persistent) {
+                    time_trace = stats != nullptr;
+                    launch_persistent(scene, V8, R, n_work * (uint32_t)streams, stream, count, time_trace);
+                    launches = scene->pt_passes;
+                } else {
                 time_trace = stats != nullptr && wavefront_rounds(V8, R) * (size_t)wavefront_pipelines(n_work * (uint32_t)streams) <= 65536;
                 launch_wavefront(scene, V8, R, n_work * (uint32_t)streams, stream, count, time_trace);
                 launches = (uint32_t)scene->wf_pipes * (1 + 2 * (uint32_t)wavefront_rounds(V8, R));
+                }
                 if (streams > 1) {
                     hipLaunchKernelGGL(dev::wf_reduce_streams_kernel, dim3((R.n_pixslots + 255u) / 256u), dim3(256), 0, stream, R);
                     HIP_CHECK(hipGetLastError());
@@ -656,9 +741,24 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (own_rgb) HIP_CHECK(hipMemcpyAsync(out_rgb, d_rgb, elems * sizeof(float), hipMemcpyDeviceToHost, stream));
         if (own_rgb8) HIP_CHECK(hipMemcpyAsync(out_rgb8, d_rgb8, elems, hipMemcpyDeviceToHost, stream));
         unsigned long long h_cnt[64] = {0};
-        if (count) HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 512, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 512, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
-        if (count && use_wavefront && blocks) { // queries = lengths of the per-round queues
+        use_persistent = use_persistent && use_wavefront && blocks;
+        scene->pipeline = use_persistent ? RT_PIPELINE_PERSISTENT : (use_wavefront && blocks ? RT_PIPELINE_ROUNDS : RT_PIPELINE_SINGLE);
+        if (use_persistent) {
+            if (h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");
+            h_cnt[0] -= h_cnt[10] < h_cnt[0] ? h_cnt[10] : h_cnt[0]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
+            if (getenv("RTAMD_DEBUG_COUNTERS") && scene->d_pt_debug && scene->pt_blocks <= 1024) {
+                std::vector<unsigned long long> dbg((size_t)scene->pt_blocks * 3);
+                HIP_CHECK(hipMemcpy(dbg.data(), scene->d_pt_debug, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, tmin = ~0ull, tmax = 0; double tsum = 0;
+                for (uint32_t b = 0; b < scene->pt_blocks; b++) if (dbg[3 * b] && dbg[3 * b] < t0) t0 = dbg[3 * b];
+                for (uint32_t b = 0; b < scene->pt_blocks; b++) { unsigned long long e = dbg[3 * b + 1] - t0; tmin = e < tmin ? e : tmin; tmax = e > tmax ? e : tmax; tsum += (double)e; }
+                fprintf(stderr, "[rtamd] persistent kernel (last pass): %u workgroups, exit times min / mean / max = %.3f / %.3f / %.3f ms after the first start; exact closest hits %llu, exact light sums %llu of %llu + %llu queries\n",
+                        scene->pt_blocks, tmin * 1e-5, tsum / scene->pt_blocks * 1e-5, tmax * 1e-5, h_cnt[12], h_cnt[13], h_cnt[0], h_cnt[1]);
+            }
+        }
+        if (count && use_wavefront && blocks && !use_persistent) { // queries = lengths of the per-round queues
             size_t rounds = wavefront_rounds(V8, R);
             std::vector<uint32_t> ctr(scene->wf_ctr_block * scene->wf_pipes);
             HIP_CHECK(hipMemcpy(ctr.data(), scene->wf.ctr, ctr.size() * 4, hipMemcpyDeviceToHost));
@@ -680,8 +780,6 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (count && getenv("RTAMD_DEBUG_COUNTERS"))
             fprintf(stderr, "[rtamd] light queries finished by the exact kernel: %llu of %llu; trace kernel: wave node-iterations %llu, leaf phases %llu (lanes %llu), refills %llu; lane node visits %llu, tri tests %llu\n",
                     h_cnt[11], h_cnt[1], h_cnt[4], h_cnt[5], h_cnt[6], h_cnt[7], h_cnt[8], h_cnt[9]);
-        if (own_rgb) { (void)hipFree(d_rgb); own_rgb = false; }
-        if (own_rgb8) { (void)hipFree(d_rgb8); own_rgb8 = false; }
         if (stats) {
             float ms = 0;
             HIP_CHECK(hipEventElapsedTime(&ms, scene->ev_start, scene->ev_stop));
@@ -689,7 +787,13 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->kernel_ms = ms;
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
-            if (use_wavefront && blocks && time_trace) {
+            stats->pipeline = (uint32_t)scene->pipeline;
+            if (use_persistent) {
+                double sum = 0;
+                for (uint32_t pp = 0; time_trace && pp < scene->pt_passes; pp++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * pp], scene->ev_pool[2 * pp + 1])); sum += e; }
+                stats->dominant_kernel_ms = time_trace ? sum : ms; stats->dominant_kernel_launches = scene->pt_passes;
+                stats->exact_closest_hits = h_cnt[12]; stats->exact_light_sums = h_cnt[13];
+            } else if (use_wavefront && blocks && time_trace) {
                 size_t rounds = wavefront_rounds(V8, R);
                 double sum = 0;
                 const size_t n_launch = rounds * (size_t)scene->wf_pipes; // with more than one pipeline a launch shares the GPU with the other pipelines' kernels
@@ -724,9 +828,9 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         }
         return RT_OK;
     } catch (const HipError &e) {
-        if (own_rgb) (void)hipFree(d_rgb);
-        if (own_rgb8) (void)hipFree(d_rgb8);
         return fail(RT_ERR_HIP, e.what());
+    } catch (const std::exception &e) { // e.g. std::bad_alloc from the host-side vectors: nothing crosses the C boundary
+        return fail(RT_ERR_INVALID_ARG, std::string("rt_render: ") + e.what());
     }
 }
 

@@ -17,13 +17,13 @@ def test_library_exports_every_declared_symbol(rt):
     assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(rt.lib, name), f"librtamd.so does not export {name}"
-    assert rt.lib.rt_abi_version() == 3
+    assert rt.lib.rt_abi_version() == 4
 
 
 def test_struct_sizes_match_header(rt):
     # sizes the C side checks through struct_size; a mismatch means the ctypes mirror drifted
     assert C.sizeof(rt.rt_material) == 56 and C.sizeof(rt.rt_render_params) == 64
-    assert C.sizeof(rt.rt_scene_desc) % 8 == 0
+    assert C.sizeof(rt.rt_scene_desc) % 8 == 0 and C.sizeof(rt.rt_stats) == 96
 
 
 def test_gltf_loader_sphere(rt, sphere_scene):

@@ -32,7 +32,7 @@ def _scene(rt, tris, mats, mat_idx, bg=(0.05, 0.1, 0.2)):
 
 
 def _check(rt, sd, w, h, spp, depth=0, tag=""):
-    for kernel in ("wavefront", "mega"):
+    for kernel in ("persistent", "wavefront", "mega"):
         import os
         os.environ["RTAMD_KERNEL"] = kernel
         scene = rt.Scene(sd)
@@ -70,11 +70,13 @@ def test_degenerate_triangles(rt):
     _check(rt, sd, 48, 36, 6, tag="degenerate")
 
 
-def test_emissive_point_light_known_box_rounding_divergence(rt):
+def test_emissive_point_light_box_rounding(rt):
     """An emissive zero-area triangle makes light sampling aim rays EXACTLY at a vertex, i.e. through the corner of
     light-BVH boxes.  There the reference's own slab test (6 divisions on a re-centred box, hw8/src/primitives.cpp:29-53)
-    rejects a box by one ulp although the ray hits a triangle inside it, while this implementation's conservative padded
-    test keeps it (known divergences).  The random stream stays in sync; a handful of samples differ."""
+    rejects a box by one ulp although the ray hits a triangle inside it, while a conservative padded test keeps it.
+    The persistent pipeline (default) sends such hits — and only those — through walks with the reference's own box
+    arithmetic and must reproduce the oracle bit for bit; the round pipeline and the megakernel keep the padded test's
+    answer (a handful of samples differ, the random stream stays in sync)."""
     import os
     sd0 = pin_cases.random_triangle_scene(n=120, seed=8)
     pos = sd0.positions.copy().reshape(-1, 3, 3)
@@ -92,8 +94,16 @@ def test_emissive_point_light_known_box_rounding_divergence(rt):
     os.environ.pop("RTAMD_KERNEL", None)
     assert np.array_equal(imgs["wavefront"], imgs["mega"], equal_nan=True)
     bad = int((np.abs(imgs["mega"].astype(np.float64) - ref).max(axis=2) > 1e-3).sum())
-    print(f"emissive point light: {bad} of {48 * 36} pixels differ from the oracle")
+    print(f"emissive point light: {bad} of {48 * 36} pixels differ from the oracle with the padded box test")
     assert bad <= 10
+    os.environ["RTAMD_KERNEL"] = "persistent"
+    scene = rt.Scene(sd)
+    rgb, _, st = scene.render(48, 36, 6)
+    scene.close()
+    os.environ.pop("RTAMD_KERNEL", None)
+    print(f"persistent pipeline: exact closest hits {st.exact_closest_hits}, exact light sums {st.exact_light_sums} of {st.closest_hit_queries} + {st.light_pdf_queries} queries")
+    assert st.pipeline == rt.RT_PIPELINE_PERSISTENT and st.exact_light_sums > 0
+    assert np.array_equal(rgb, ref, equal_nan=True)
 
 
 @pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 5, 0), (9, 7, 2, 1), (8, 8, 3, 2), (33, 5, 2, 16), (24, 16, 1, 6)])
@@ -134,6 +144,7 @@ def test_spill_variant_of_the_traversal_kernel(rt, sphere_scene, monkeypatch):
     for sd, (w, h, spp) in ((sphere_scene, (64, 48, 5)), (pin_cases.random_triangle_scene(n=700, seed=21), (72, 48, 5))):
         scene = rt.Scene(sd)
         assert scene.info().bvh_depth > 3
+        monkeypatch.setenv("RTAMD_KERNEL", "wavefront")  # the round pipeline owns the spill variant (and serves deeper trees)
         ref, ref8, st0 = scene.render(w, h, spp)
         monkeypatch.setenv("RTAMD_WF_LDS_STACK", "3")
         rgb, rgb8, st = scene.render(w, h, spp)
@@ -174,6 +185,7 @@ def test_independent_pipelines_do_not_change_pixels(rt, sphere_scene, monkeypatc
     sd = pin_cases.random_triangle_scene(n=400, seed=33)
     scene = rt.Scene(sd)
     w, h, spp = 88, 56, 6
+    monkeypatch.setenv("RTAMD_KERNEL", "wavefront")
     monkeypatch.setenv("RTAMD_WF_PIPELINES", "1")
     ref, ref8, st1 = scene.render(w, h, spp, counters=True)
     shard_ref, _, _ = scene.render(w, h, spp, shard_index=1, shard_count=3, tile=16)
@@ -195,12 +207,18 @@ def test_independent_pipelines_do_not_change_pixels(rt, sphere_scene, monkeypatc
     scene.close()
 
 
-def test_more_rounds_than_the_per_launch_event_pool(rt, sphere_scene):
+def test_more_rounds_than_the_per_launch_event_pool(rt, sphere_scene, monkeypatch):
     """12,000 spp at depth 6 = 72,000 wavefront rounds: beyond 65,536 rounds the driver stops bracketing every traverse launch with
     HIP events (rt_stats.dominant_kernel_ms then falls back to the whole kernel time); pixels are unaffected."""
+    monkeypatch.setenv("RTAMD_KERNEL", "wavefront")
     scene = rt.Scene(sphere_scene)
     rgb, rgb8, st = scene.render(8, 8, 12000)
     scene.close()
+    monkeypatch.delenv("RTAMD_KERNEL")
+    scene = rt.Scene(sphere_scene)
+    prgb, prgb8, pst = scene.render(8, 8, 12000)  # the persistent pipeline: one launch, the same 12,000 serial samples per pixel
+    scene.close()
+    assert pst.launches == 1 and pst.pipeline == rt.RT_PIPELINE_PERSISTENT and np.array_equal(prgb, rgb, equal_nan=True) and np.array_equal(prgb8, rgb8)
     ref, ref8, _ = oracle_lib.Hw8Oracle(sphere_scene).render(8, 8, 12000)
     assert st.launches == 1 + 2 * 72000 and st.dominant_kernel_launches == st.launches and st.dominant_kernel_ms == st.kernel_ms
     assert np.array_equal(rgb, ref, equal_nan=True) and np.array_equal(rgb8, ref8)

@@ -16,7 +16,7 @@ CASES = {"practice7_1": (lambda: pin_cases.load_hw7("practice7_1"), 48, 48, 8), 
          "soup_as_hw7": (lambda: pin_cases.as_hw7(pin_cases.random_triangle_scene()), 40, 32, 6)}
 
 
-@pytest.mark.parametrize("kernel", ["wavefront", "mega"])
+@pytest.mark.parametrize("kernel", ["persistent", "wavefront", "mega"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hw7_matches_the_reference_radiance(rt, monkeypatch, name, kernel):
     monkeypatch.setenv("RTAMD_KERNEL", kernel)

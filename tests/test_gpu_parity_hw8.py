@@ -14,7 +14,7 @@ def _rmse(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-@pytest.fixture(params=["wavefront", "mega"])
+@pytest.fixture(params=["persistent", "wavefront", "mega"])
 def kernel(request, monkeypatch):
     """Both kernel organisations must give the same pixels (RTAMD_KERNEL is read at render time)."""
     monkeypatch.setenv("RTAMD_KERNEL", request.param)

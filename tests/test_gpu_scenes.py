@@ -29,7 +29,7 @@ def _report(tag, rgb, ref, rgb8=None, ref8=None):
     return rmse, bad
 
 
-@pytest.fixture(params=["wavefront", "mega"])
+@pytest.fixture(params=["persistent", "wavefront", "mega"])
 def kernel(request, monkeypatch):
     monkeypatch.setenv("RTAMD_KERNEL", request.param)
     return request.param
@@ -72,6 +72,12 @@ def test_without_the_deepest_level_shortcut_the_pixels_are_the_same(rt, small_ro
     ref, ref8, _ = oracle_lib.Hw8Oracle(small_room).render(96, 54, 7)
     monkeypatch.setenv("RTAMD_NO_LAST_LEVEL_SHORTCUT", "1")
     scene = rt.Scene(small_room)
+    rgb, rgb8, st = scene.render(96, 54, 7)   # persistent pipeline (default)
+    rmse, bad = _report("room, shortcut off, persistent", rgb, ref, rgb8, ref8)
+    assert st.pipeline == rt.RT_PIPELINE_PERSISTENT and rmse < RMSE_TOL and bad <= 3
+    scene.close()
+    monkeypatch.setenv("RTAMD_KERNEL", "wavefront")
+    scene = rt.Scene(small_room)
     rgb, rgb8, st = scene.render(96, 54, 7)
     monkeypatch.delenv("RTAMD_NO_LAST_LEVEL_SHORTCUT")
     rmse, bad = _report("room, shortcut off", rgb, ref, rgb8, ref8)
@@ -82,8 +88,13 @@ def test_without_the_deepest_level_shortcut_the_pixels_are_the_same(rt, small_ro
     sd.materials[0].metallic_factor = 1.5
     sd._build_desc()
     scene = rt.Scene(sd)
-    rgb, rgb8, st = scene.render(64, 48, 5)
     ref, ref8, _ = oracle_lib.Hw8Oracle(sd).render(64, 48, 5)
+    monkeypatch.delenv("RTAMD_KERNEL")
+    rgb, rgb8, st = scene.render(64, 48, 5)
+    rmse, bad = _report("soup with metallicFactor 1.5, persistent", rgb, ref, rgb8, ref8)
+    assert st.pipeline == rt.RT_PIPELINE_PERSISTENT and rmse < RMSE_TOL and bad <= 3
+    monkeypatch.setenv("RTAMD_KERNEL", "wavefront")
+    rgb, rgb8, st = scene.render(64, 48, 5)
     rmse, bad = _report("soup with metallicFactor 1.5", rgb, ref, rgb8, ref8)
     assert st.launches == 1 + 2 * 5 * 7 and rmse < RMSE_TOL and bad <= 3
     scene.close()

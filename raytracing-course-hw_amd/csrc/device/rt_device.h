@@ -160,6 +160,27 @@ RT_DEV bool tri_test(const TriIsect &T, F3 o, F3 d, float &t, float &u, float &v
     return true;
 }
 
+// tri_test for a closest-hit walk that already holds a hit at best_t: a triangle whose plane lies beyond best_t (by more than
+// the walkers' tie tolerance) cannot become the closest hit whatever its barycentrics are, so their two divisions are skipped.
+// Exactly the same accept / reject decisions as tri_test for every triangle that could still matter.
+RT_DEV bool tri_test_closer(const TriIsect &T, F3 o, F3 d, float best_t, float &t, float &u, float &v, bool &inside) {
+    F3 a = f3(T.ax, T.ay, T.az), n = f3(T.nx, T.ny, T.nz);
+    F3 ro = o - a;
+    float dn = dot(d, n);
+    t = -dot(ro, n) / dn;
+    if (!(t > 0 && t < RT_T_MAX)) return false;
+    if (t > best_t + 4.8e-7f * t) return false;
+    inside = dn > 0;
+    F3 p = ro + t * d;
+    float c1 = RT_MAGIC1_0 * p.x + RT_MAGIC1_1 * p.y + RT_MAGIC1_2 * p.z;
+    float c2 = RT_MAGIC2_0 * p.x + RT_MAGIC2_1 * p.y + RT_MAGIC2_2 * p.z;
+    float yy = (c1 * T.a2 - c2 * T.a1) / T.den;
+    float xx = T.a2 == 0 ? (c1 - T.b1 * yy) / T.a1 : (c2 - T.b2 * yy) / T.a2;
+    u = xx; v = yy;
+    if (u < 0 || v < 0 || u + v > 1) return false;
+    return true;
+}
+
 RT_DEV TriIsect load_isect(const TriIsect *p) {
     const float4 *q = reinterpret_cast<const float4 *>(p);
     float4 a = q[0], b = q[1], c = q[2];
@@ -191,6 +212,30 @@ RT_DEV bool slab_test(float4 lo, float4 hi, const RayInv &r, float tbest, float 
     float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
     tmin = fmaf(-fabsf(tmin), 4.8e-7f, tmin);
     tmax = fmaf(fabsf(tmax), 4.8e-7f, tmax);
+    tnear = tmin;
+    return (tmin <= tmax) & (tmax >= 0.f) & (tmin <= tbest);
+}
+
+// The same test with one fused multiply-add per plane: t = lo * inv + (-o * inv).  The rounding of the precomputed -o * inv
+// adds an ABSOLUTE error of up to 2^-24 |o_k inv_k| per axis, covered by the per-ray pad `e` = 2^-23 max_k |o_k inv_k|
+// on top of the relative widening.  Half the multiplies and subtractions of slab_test per box.
+struct RayFma { F3 inv, noi; float e; };
+RT_DEV RayFma make_ray_fma(F3 o, F3 d) {
+    RayInv r = make_ray_inv(o, d);
+    RayFma f;
+    f.inv = r.inv;
+    f.noi = f3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+    f.e = 1.1920929e-07f * fmaxf(fmaxf(fabsf(f.noi.x), fabsf(f.noi.y)), fabsf(f.noi.z));
+    return f;
+}
+RT_DEV bool slab_test_fma(float4 lo, float4 hi, const RayFma &r, float tbest, float &tnear) {
+    float t0x = fmaf(lo.x, r.inv.x, r.noi.x), t1x = fmaf(hi.x, r.inv.x, r.noi.x);
+    float t0y = fmaf(lo.y, r.inv.y, r.noi.y), t1y = fmaf(hi.y, r.inv.y, r.noi.y);
+    float t0z = fmaf(lo.z, r.inv.z, r.noi.z), t1z = fmaf(hi.z, r.inv.z, r.noi.z);
+    float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    tmin = fmaf(-fabsf(tmin), 4.8e-7f, tmin) - r.e;
+    tmax = fmaf(fabsf(tmax), 4.8e-7f, tmax) + r.e;
     tnear = tmin;
     return (tmin <= tmax) & (tmax >= 0.f) & (tmin <= tbest);
 }

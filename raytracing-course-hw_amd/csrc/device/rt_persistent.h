@@ -58,11 +58,19 @@ struct PtShared {
     uint32_t stack[PT_WAVES][WF_STACK][64];   // per-lane traversal stack columns, one area per wave
     uint32_t need[5][PT_NW];
     uint32_t pending[PT_NW * 2];              // 2 bits per path
+    uint32_t groups[PT_MAX_PATHS / 64];       // local 64-slot group -> group of the pass (8x8 sub-tile)
+    uint32_t cost[PT_MAX_PATHS / 64];         // shaded hits per local group in this launch: the load measure the frame is re-dealt by
     int cnt[16];
 };
 
 struct PtParams {
     uint32_t n_groups;                // 64-slot groups (8x8 sub-tiles) of this pass
+    // Which groups a workgroup owns: group_ids[group_ofs[b] .. group_ofs[b + 1]) when group_ofs is set (the host's re-deal after
+    // the first phase of a frame), else b, b + n_blocks, b + 2 n_blocks, ...; `resume` = the paths carry on from their records
+    // (a later phase) instead of being seeded; group_cost[g] receives the number of hits shaded for group g in this launch.
+    const uint32_t *group_ofs, *group_ids;
+    uint32_t *group_cost;
+    uint32_t resume;
     int refill, leaf_batch;           // as in rt_wavefront.h (leaf_batch = batch | share << 16)
     int shade_thr0, shade_thr_step;   // wave w stops refilling its walkers when need_shade holds >= thr0 + w * step paths
     int cost_t, cost_l;               // relative cost of a closest-hit / light query (walker split)
@@ -71,44 +79,65 @@ struct PtParams {
     unsigned long long *debug;        // nullable: per workgroup {start time, exit time of its last wave (100 MHz ticks), paths}
 };
 
+// COUNT builds only: where a wave's time goes (shader-clock cycles per role) and how full its walker iterations are
+struct PtProf {
+    unsigned long long t_trace = 0, t_light = 0, t_shade = 0, t_exact = 0, t_idle = 0;
+    unsigned long long trace_iters = 0, trace_lane_iters = 0, light_iters = 0, light_lane_iters = 0, stints = 0, shade_batches = 0, shade_items = 0;
+};
+
 // wave-uniform state
 struct PtWave {
     uint32_t nw, n_local, n_blocks, block;
     uint32_t cur[5];
-    uint32_t rr;
 };
 
-RT_DEV uint32_t pt_slot(const PtWave &w, uint32_t l) { return (((l >> 6) * w.n_blocks + w.block) << 6) | (l & 63u); }
+RT_DEV uint32_t pt_slot(const PtShared &sh, uint32_t l) { return (sh.groups[l >> 6] << 6) | (l & 63u); }
 RT_DEV int pt_count(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // a fresh LDS read each time
 
-// Claims one set bit per wanting lane.  Lane i looks at word (cursor + i) mod nw; inside a word the bits are served from a
-// rotating position, so no path waits behind a neighbour that is always ready.  Returns the local path index or PT_NONE.
-RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &cursor, uint32_t &rr, bool want) {
+// Hands paths to the lanes that want one.  The wave reads 64 bitmap words at once (lane i: word cursor + i), then takes whole
+// words in order — ONE atomicAnd per word by lane 0 — and deals the claimed bits to the wanting lanes by rank, so a wave that
+// wants 64 paths from a dense queue gets the two words of one 8x8 sub-tile (coherent rays) for two LDS atomics.  A word that
+// holds more paths than are wanted keeps its upper bits and the cursor stays on it, so the next request starts there (no
+// path is passed over).  Returns the local path index or PT_NONE.
+RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &cursor, bool want) {
     const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long wantmask = __ballot(want);
+    const int need = __popcll(wantmask);
+    const int my_rank = __popcll(wantmask & ((1ull << lane) - 1ull));
     uint32_t got = PT_NONE;
-    const uint32_t rot = rr & 31u;
-    rr += 7u;
-    for (uint32_t swept = 0; swept < nw; swept += 64u) {
-        const bool trying = want && got == PT_NONE;
-        if (!__ballot(trying)) break;
-        uint32_t w = cursor + lane, skip = 0;
+    int have = 0;
+    for (uint32_t swept = 0; swept < nw && have < need; swept += 64u) {
+        uint32_t w = cursor + lane;
+        bool valid = true;
         if (nw >= 64u) { if (w >= nw) w -= nw; }
-        else { skip = lane / nw; w = w % nw; }          // several lanes per word: the k-th of them takes the k-th set bit
-        if (trying) {
-            const uint32_t v = bm[w];
-            uint32_t r = (v >> rot) | (v << ((32u - rot) & 31u));
-            for (uint32_t i = 0; i < skip && r; i++) r &= r - 1u;
-            if (r) {
-                const uint32_t b = ((uint32_t)__ffs((int)r) - 1u + rot) & 31u;
-                const uint32_t old = atomicAnd(&bm[w], ~(1u << b));
-                if (old & (1u << b)) got = w * 32u + b;
+        else { valid = lane < nw; w = w % nw; }
+        const uint32_t v = valid ? bm[w] : 0u;
+        unsigned long long nz = __ballot(v != 0u);
+        uint32_t next_cursor = cursor + 64u;
+        while (nz && have < need) {
+            const int j = __ffsll((long long)nz) - 1;
+            nz &= nz - 1ull;
+            const uint32_t vj = (uint32_t)__shfl((int)v, j), wj = (uint32_t)__shfl((int)w, j);
+            uint32_t rest = vj;                                   // the lowest (need - have) set bits of vj
+            for (int n = need - have; n > 0 && rest; n--) rest &= rest - 1u;
+            const uint32_t take = vj & ~rest;
+            uint32_t old = 0;
+            if (lane == 0) old = atomicAnd(&bm[wj], ~take);
+            old = (uint32_t)__shfl((int)old, 0) & take;           // the bits this wave really claimed
+            const int c = __popc(old);
+            if (want && my_rank >= have && my_rank < have + c) {
+                uint32_t bits = old;
+                for (int k = my_rank - have; k > 0; k--) bits &= bits - 1u;
+                got = wj * 32u + (uint32_t)__ffs((int)bits) - 1u;
             }
+            have += c;
+            if (rest) next_cursor = wj;                          // paths left in this word: come back to it first
+            else if (have >= need) next_cursor = wj + 1u;
         }
-        cursor += 64u;
+        cursor = next_cursor;
         if (cursor >= nw) cursor %= nw;
     }
-    const unsigned long long m = __ballot(got != PT_NONE);
-    if (m && lane == 0) atomicSub(cnt, (int)__popcll(m));
+    if (have && lane == 0) atomicSub(cnt, have);
     return got;
 }
 
@@ -275,33 +304,36 @@ RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d,
 // the LDS hand-off with one workgroup-scope release.
 template <bool COUNT>
 RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
-                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
+                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
     bool active = false, tie = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
     int sp = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayInv ray = make_ray_inv(o, d);
+    RayFma ray = make_ray_fma(o, d);
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
     for (;;) {
-        if (__ballot(fin != PT_NONE)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
-            fin = PT_NONE;
-        }
         const unsigned long long idle = __ballot(!active);
-        if (idle && refill_ok && (__popcll(idle) >= P.refill || idle == ~0ull)) {
-            if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;      // shaders are behind: drain, then help them
+        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+            // Hand-off point.  Finished lanes are published here and not the moment they finish: the release (a wait for the
+            // wave's outstanding record stores) is paid once per refill, when the stores have long landed, not once per walk.
+            if (__ballot(fin != PT_NONE)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
+                fin = PT_NONE;
+            }
+            if (!refill_ok) {}
+            else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;      // shaders are behind: drain, then help them
             else if (pt_count(&sh.cnt[PT_Q_TRACE]) > 0) {
-                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], wv.rr, !active);
+                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 n_queries += __popcll(__ballot(got != PT_NONE));
                 if (got != PT_NONE) {
-                    l = got; slot = pt_slot(wv, l);
+                    l = got; slot = pt_slot(sh, l);
                     const float4 *r = wf_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
-                    ray = make_ray_inv(o, d);
+                    ray = make_ray_fma(o, d);
                     cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; tie = false;
                     active = true;
                 }
@@ -313,13 +345,14 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         for (;;) { // phase 1: inner nodes
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (COUNT) { prof.trace_iters++; prof.trace_lane_iters += __popcll(__ballot(inner)); }
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
-                bool h0 = slab_test(lo0, hi0, ray, best_t, n0);
-                bool h1 = slab_test(lo1, hi1, ray, best_t, n1);
+                bool h0 = slab_test_fma(lo0, hi0, ray, best_t, n0);
+                bool h1 = slab_test_fma(lo1, hi1, ray, best_t, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) {
                     bool swap = n1 < n0;
@@ -340,7 +373,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     TriIsect T = load_isect(S.tri_isect + i);
                     if (COUNT) n_tris++;
                     float t, u, v; bool inside;
-                    if (tri_test(T, o, d, t, u, v, inside)) {
+                    if (tri_test_closer(T, o, d, best_t, t, u, v, inside)) {
                         // a second hit within the slab test's own tolerance of the best one: the reference's pruning may
                         // order the two differently (bvh.h:118), so the exact walk decides
                         const bool close = fabsf(t - best_t) <= 4.8e-7f * fmaxf(t, best_t);
@@ -365,13 +398,13 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 // ---- light-sum walker (wf_light_loop_lean of rt_wavefront.h fed from the need_light bitmap) ----------------------------------
 template <bool COUNT>
 RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
-                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
+                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
     bool active = false, overflow = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE;
     int sp = 0, k = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayInv ray = make_ray_inv(o, d);
+    RayFma ray = make_ray_fma(o, d);
     auto finish = [&]() {
         active = false;
         if (overflow) { slow = l; return; }
@@ -406,25 +439,26 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         fin = l;
     };
     for (;;) {
-        if (__ballot(fin != PT_NONE || slow != PT_NONE)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE);
-            pt_push(sh, PT_Q_XLIGHT, slow, slow != PT_NONE);
-            fin = PT_NONE; slow = PT_NONE;
-        }
         const unsigned long long idle = __ballot(!active);
-        if (idle && refill_ok && (__popcll(idle) >= P.refill || idle == ~0ull)) {
-            if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
+        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+            if (__ballot(fin != PT_NONE || slow != PT_NONE)) { // hand-off point, see pt_trace_stint
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE);
+                pt_push(sh, PT_Q_XLIGHT, slow, slow != PT_NONE);
+                fin = PT_NONE; slow = PT_NONE;
+            }
+            if (!refill_ok) {}
+            else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
             else if (pt_count(&sh.cnt[PT_Q_LIGHT]) > 0) {
-                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], wv.rr, !active);
+                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 n_queries += __popcll(__ballot(got != PT_NONE));
                 if (got != PT_NONE) {
-                    l = got; slot = pt_slot(wv, l);
+                    l = got; slot = pt_slot(sh, l);
                     const float4 *r = wf_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
-                    ray = make_ray_inv(o, d);
+                    ray = make_ray_fma(o, d);
                     cur = 0; sp = 0; k = 0; overflow = false;
                     active = true;
                 }
@@ -436,13 +470,14 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         for (;;) { // phase 1: inner nodes
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (COUNT) { prof.light_iters++; prof.light_lane_iters += __popcll(__ballot(inner)); }
             if (inner) {
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
-                bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
-                bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+                bool h0 = slab_test_fma(lo0, hi0, ray, RT_T_MAX, n0);
+                bool h1 = slab_test_fma(lo1, hi1, ray, RT_T_MAX, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
                 else if (h0) cur = c0;
@@ -503,24 +538,26 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     PtWave wv;
     wv.n_blocks = gridDim.x; wv.block = blockIdx.x;
-    const uint32_t n_local_groups = P.n_groups > wv.block ? (P.n_groups - wv.block + wv.n_blocks - 1u) / wv.n_blocks : 0u;
+    const uint32_t first_group = P.group_ofs ? P.group_ofs[wv.block] : 0u;
+    const uint32_t n_local_groups = P.group_ofs ? P.group_ofs[wv.block + 1u] - first_group
+                                                : (P.n_groups > wv.block ? (P.n_groups - wv.block + wv.n_blocks - 1u) / wv.n_blocks : 0u);
     wv.n_local = n_local_groups * 64u;
     wv.nw = n_local_groups * 2u;
     if (wv.n_local == 0u) return;
     if (P.debug && tid == 0) { P.debug[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); P.debug[3 * blockIdx.x + 2] = wv.n_local; }
     for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
-    wv.rr = wave * 5u;
 
     // ---- init: seed every pixel of this workgroup, first camera ray (wf_init_kernel of rt_wavefront.h) -----------------------
     for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
     for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
+    for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
     if (tid < 16u) sh.cnt[tid] = 0;
     __syncthreads();
     for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) {
         const uint32_t l = base + tid;
         bool started = false;
         if (l < wv.n_local) {
-            const uint32_t slot = pt_slot(wv, l), gslot = slot + W.slot_base;
+            const uint32_t slot = pt_slot(sh, l), gslot = slot + W.slot_base;
             int x, y; bool inside; size_t out_index;
             wf_slot_to_pixel(R, gslot, x, y, inside, out_index);
             if (!inside) { // padding of a border tile in the compact shard layout
@@ -528,6 +565,11 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
                     if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
                     if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
                 }
+            } else if (P.resume) {
+                // a later phase of the frame: the record holds the pixel sum, the random stream and the parked camera ray
+                const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]);
+                started = ((packed >> 6) & WF_SAMPLE_MASK) < (uint32_t)R.samples;
+                if (started) atomicOr(&sh.pending[l >> 4], PT_BIT_T << ((l & 15u) * 2u));
             } else {
                 Rng rng;
                 rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (gslot / R.n_pixslots) * R.seed_stride : 0u)); // sceneio.cpp:389-391
@@ -555,6 +597,9 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
     const int shade_thr = P.shade_thr0 + (int)wave * P.shade_thr_step;
     unsigned long long n_closest = 0, n_light = 0, n_nodes = 0, n_tris = 0, n_xtrace = 0, n_xlight = 0, n_discarded = 0;
     uint32_t idle_spins = 0;
+    PtProf prof;
+    unsigned long long t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto lap = [&](unsigned long long &acc) { if (COUNT) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc += t - t_mark; t_mark = t; } };
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { // safety net: never hang the GPU; the host reports the error
@@ -566,10 +611,10 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
         if (nx > 0) {
             // exact role: one lane per query, the reference's own box arithmetic over the reference trees
             uint32_t xstack[RT_STACK_SIZE];
-            uint32_t got = pt_pop(sh.need[PT_Q_XLIGHT], &sh.cnt[PT_Q_XLIGHT], wv.nw, wv.cur[PT_Q_XLIGHT], wv.rr, true);
+            uint32_t got = pt_pop(sh.need[PT_Q_XLIGHT], &sh.cnt[PT_Q_XLIGHT], wv.nw, wv.cur[PT_Q_XLIGHT], true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (got != PT_NONE) {
-                const uint32_t slot = pt_slot(wv, got);
+                const uint32_t slot = pt_slot(sh, got);
                 const float4 *r = wf_rec(W, slot);
                 float4 q0 = r[0], q1 = r[1];
                 const F3 x = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
@@ -583,10 +628,10 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             n_xlight += __popcll(__ballot(got != PT_NONE));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
-            got = pt_pop(sh.need[PT_Q_XTRACE], &sh.cnt[PT_Q_XTRACE], wv.nw, wv.cur[PT_Q_XTRACE], wv.rr, true);
+            got = pt_pop(sh.need[PT_Q_XTRACE], &sh.cnt[PT_Q_XTRACE], wv.nw, wv.cur[PT_Q_XTRACE], true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (got != PT_NONE) {
-                const uint32_t slot = pt_slot(wv, got);
+                const uint32_t slot = pt_slot(sh, got);
                 float4 *r = wf_rec(W, slot);
                 float4 q0 = r[0], q1 = r[1];
                 float bt, bu, bv; uint32_t hit;
@@ -599,15 +644,16 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
             idle_spins = 0;
+            lap(prof.t_exact);
             continue;
         }
         // shaders first when a full wave of paths waits (or when it is all there is to do)
         if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
-            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], wv.rr, true);
+            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             int todo = 0;
             bool discarded = false;
-            if (got != PT_NONE) todo = pt_shade_item(S, R, W, pt_slot(wv, got), discarded);
+            if (got != PT_NONE) todo = pt_shade_item(S, R, W, pt_slot(sh, got), discarded);
             n_discarded += __popcll(__ballot(discarded));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const bool next = got != PT_NONE && (todo & WF_NEXT_TRACE), with_light = next && (todo & WF_NEXT_LIGHT);
@@ -615,9 +661,12 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             pt_push(sh, PT_Q_TRACE, got, next);
             pt_push(sh, PT_Q_LIGHT, got, with_light);
             pt_push(sh, PT_Q_XTRACE, got, got != PT_NONE && todo == PT_SHADE_EXACT);
-            const unsigned long long done = __ballot(got != PT_NONE && todo == 0);
+            if (got != PT_NONE && todo != PT_SHADE_EXACT) atomicAdd(&sh.cost[got >> 6], 1u);
+            const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == WF_PARKED)); // finished, or parked for the next phase
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;
+            if (COUNT) { prof.shade_batches++; prof.shade_items += __popcll(__ballot(got != PT_NONE)); }
+            lap(prof.t_shade);
             continue;
         }
         if (nt + nl > 0) {
@@ -625,23 +674,31 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             const long long wt = (long long)nt * P.cost_t * (pt_count(&sh.cnt[PT_W_LIGHT]) + 1), wl = (long long)nl * P.cost_l * (pt_count(&sh.cnt[PT_W_TRACE]) + 1);
             if (nl == 0 || (nt > 0 && wt >= wl)) {
                 if (lane == 0) atomicAdd(&sh.cnt[PT_W_TRACE], 1);
-                pt_trace_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_closest, n_nodes, n_tris);
+                pt_trace_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_closest, n_nodes, n_tris, prof);
                 if (lane == 0) atomicSub(&sh.cnt[PT_W_TRACE], 1);
+                lap(prof.t_trace);
             } else {
                 if (lane == 0) atomicAdd(&sh.cnt[PT_W_LIGHT], 1);
-                pt_light_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_light, n_nodes, n_tris);
+                pt_light_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_light, n_nodes, n_tris, prof);
                 if (lane == 0) atomicSub(&sh.cnt[PT_W_LIGHT], 1);
+                lap(prof.t_light);
             }
             idle_spins = 0;
+            if (COUNT) prof.stints++;
             continue;
         }
         if (pt_count(&sh.cnt[PT_N_LIVE]) <= 0) break;
         // paths are in flight in other waves' registers: wait for them
         __builtin_amdgcn_s_sleep(8);
+        lap(prof.t_idle);
         if (++idle_spins > (1u << 24)) { // safety net (seconds): never hang the GPU on a lost path; the host reports it
             if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
             break;
         }
+    }
+    if (P.group_cost) { // every wave leaves the loop once the workgroup's pixels are done (or at the deadline)
+        __syncthreads();
+        for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
     }
     if (lane == 0 && P.counters) {
         if (n_closest) atomicAdd(&P.counters[0], n_closest);
@@ -650,7 +707,16 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
         if (n_xtrace) atomicAdd(&P.counters[12], n_xtrace);
         if (n_xlight) atomicAdd(&P.counters[13], n_xlight);
     }
-    if (COUNT && P.counters) { atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris); }
+    if (COUNT && P.counters) {
+        atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris);
+        if (lane == 0) { // wave-level profile, words 16..27
+            atomicAdd(&P.counters[16], prof.t_trace); atomicAdd(&P.counters[17], prof.t_light); atomicAdd(&P.counters[18], prof.t_shade);
+            atomicAdd(&P.counters[19], prof.t_exact); atomicAdd(&P.counters[20], prof.t_idle);
+            atomicAdd(&P.counters[21], prof.trace_iters); atomicAdd(&P.counters[22], prof.trace_lane_iters);
+            atomicAdd(&P.counters[23], prof.light_iters); atomicAdd(&P.counters[24], prof.light_lane_iters);
+            atomicAdd(&P.counters[25], prof.stints); atomicAdd(&P.counters[26], prof.shade_batches); atomicAdd(&P.counters[27], prof.shade_items);
+        }
+    }
     if (P.debug && lane == 0) {
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         atomicMax(&P.debug[3 * blockIdx.x + 1], now);

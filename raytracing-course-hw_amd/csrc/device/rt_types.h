@@ -109,6 +109,8 @@ struct SceneView {
 
 struct RenderView {
     int32_t width, height, samples, ray_depth;
+    int32_t sample_stop;           // a path that reaches this sample index parks (its camera ray is in its record): the persistent
+                                   // pipeline renders a frame in phases and re-deals the pixels between them; = samples otherwise
     int32_t tile_w, tile_h, tiles_x, tiles_y;
     int32_t shard_index, shard_count;
     uint32_t n_shard_tiles;

@@ -115,9 +115,13 @@ RT_DEV void wf_camera_ray(const SceneView &S, const RenderView &R, Rng &rng, int
 }
 
 // End of one camera sample: fold e + m*(inner) backwards (scene.cpp:164), add to the pixel sum
-// (scene.cpp:174), then either start the next sample (returns true: the slot holds a new camera ray that wants tracing)
-// or write the finished pixel (returns false).  The pixel sum is read here, not carried through the shading code.
-RT_DEV bool wf_finish_path(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, int depth, F3 tail,
+// (scene.cpp:174), then either start the next sample (returns WF_NEXT_TRACE: the slot holds a new camera ray that wants
+// tracing; WF_PARKED instead when that sample belongs to the next phase of the frame, R.sample_stop) or write the finished
+// pixel (returns 0).  The pixel sum is read here, not carried through the shading code.
+#define WF_NEXT_TRACE 1
+#define WF_NEXT_LIGHT 2
+#define WF_PARKED 8
+RT_DEV int wf_finish_path(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, int depth, F3 tail,
                            Rng &rng, uint32_t sample) {
     F3 L = tail;
     for (int b = depth - 1; b >= 0; b--) {
@@ -137,7 +141,7 @@ RT_DEV bool wf_finish_path(const SceneView &S, const RenderView &R, const WfView
         r[0] = make_float4(o.x, o.y, o.z, d.x);
         r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
         r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(wf_pack(0, rng.has_saved, sample)));
-        return true;
+        return sample < (uint32_t)R.sample_stop ? WF_NEXT_TRACE : WF_PARKED;
     }
     if (R.streams > 1) {                                             // throughput mode: this stream's unnormalised sum
         float *o = R.partial + 3 * (size_t)(slot + W.slot_base);
@@ -149,7 +153,7 @@ RT_DEV bool wf_finish_path(const SceneView &S, const RenderView &R, const WfView
             R.out_rgb8[3 * out_index] = tonemap1(px.x); R.out_rgb8[3 * out_index + 1] = tonemap1(px.y); R.out_rgb8[3 * out_index + 2] = tonemap1(px.z);
         }
     }
-    return false;
+    return 0;
 }
 
 // ---- init: seed every pixel, first camera ray, fill the round-0 trace queue ------------------------------
@@ -606,9 +610,8 @@ __global__ __launch_bounds__(64) void wf_light_exact_kernel(SceneView S, WfView 
 
 // ---- shade: finish the pending bounce (scene.cpp:158-164), then scene.cpp:89-156 for the new hit ------------------------
 // Returns what the slot needs next: WF_NEXT_TRACE (its record holds a ray to trace: a new bounce or the next sample's camera
-// ray), | WF_NEXT_LIGHT (that ray is also a bounce's light-pdf query), or 0 (the pixel is finished and written).
-#define WF_NEXT_TRACE 1
-#define WF_NEXT_LIGHT 2
+// ray), | WF_NEXT_LIGHT (that ray is also a bounce's light-pdf query), WF_PARKED (the next sample's camera ray is in the
+// record but belongs to the frame's next phase), or 0 (the pixel is finished and written).
 RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, unsigned long long *counters, bool *discarded = nullptr) {
     float4 *r = wf_rec(W, slot);
     float4 q0 = r[0], q1 = r[1], q2 = r[2];
@@ -692,7 +695,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
             }
         }
     }
-    return wf_finish_path(S, R, W, slot, levels, tail, rng, sample) ? WF_NEXT_TRACE : 0;
+    return wf_finish_path(S, R, W, slot, levels, tail, rng, sample);
 }
 
 // Throughput mode epilogue: pixel = float(1/spp) * (sum of its K stream sums, added in stream order), then the usual tonemap.

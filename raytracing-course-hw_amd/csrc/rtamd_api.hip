@@ -2,6 +2,7 @@
 // No CPU fallback exists: every entry point that needs the GPU fails with RT_ERR_NO_DEVICE / RT_ERR_HIP
 // when HIP is unusable.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -103,8 +104,10 @@ struct rt_scene {
     std::vector<hipEvent_t> ev_pool; // brackets every launch of the dominant kernel when stats are requested
     unsigned long long *d_pt_debug = nullptr; // persistent pipeline: per workgroup {start, exit time, paths} (RTAMD_DEBUG_COUNTERS)
     float4 *pt_r0 = nullptr;         // persistent pipeline: path records of one pass
-    size_t pt_slots = 0, pt_levels = 0;
-    uint32_t pt_passes = 0, pt_blocks = 0;
+    uint32_t *pt_groups = nullptr;   // [cost per group | group_ofs (n_blocks + 1) | group_ids]: the re-deal between the phases of a frame
+    size_t pt_slots = 0, pt_levels = 0, pt_group_words = 0;
+    uint32_t pt_passes = 0, pt_blocks = 0, pt_launches = 0;
+    double pt_rebalance_ms = 0, pt_imbalance = 0;
     int pipeline = 0;                // RT_PIPELINE_* of the last render
     void free_wf() {
         for (void *p : wf_allocs) (void)hipFree(p);
@@ -116,6 +119,7 @@ struct rt_scene {
         free_wf();
         if (d_partial) (void)hipFree(d_partial);
         if (pt_r0) (void)hipFree(pt_r0);
+        if (pt_groups) (void)hipFree(pt_groups);
         if (d_pt_debug) (void)hipFree(d_pt_debug);
         for (void *p : allocations) (void)hipFree(p);
         if (ev_start) (void)hipEventDestroy(ev_start);
@@ -538,7 +542,14 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
 
 // Persistent dataflow driver (device/rt_persistent.h): ONE launch renders up to n_cus x PT_MAX_PATHS path slots; larger frames
 // (or throughput mode with many streams) take several passes over disjoint slot ranges, each a complete render of its pixels.
-// Every launch is bracketed by events when `time_trace` (ev_pool[2p], ev_pool[2p+1]).
+//
+// Load balance.  A workgroup owns its pixels for a whole launch, and pixels differ in cost (sky: one query per sample, a glossy
+// interior: up to 2 x depth), so with the plain round-robin deal of the 8x8 sub-tiles the slowest workgroup ends 3 % (1080p on
+// one GPU) to 12 % (a shard of 8) behind the mean.  A frame of >= 16 samples is therefore rendered in two phases: the first
+// 1/16 of the samples with the round-robin deal while every workgroup counts the hits it shades per sub-tile, then the host
+// re-deals the sub-tiles (longest processing time first onto the least loaded workgroup) and the second launch resumes every
+// pixel from its record (pixel sum, random stream and the parked camera ray are all there; pixels do not depend on the deal).
+// Every launch is bracketed by events when `time_trace` (ev_pool[2k], ev_pool[2k+1]).
 static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
     uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus); // one 1024-thread workgroup per CU (its LDS fills the CU)
@@ -553,12 +564,20 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
         HIP_CHECK(hipMalloc((void **)&scene->pt_r0, n_slots * (64 + 32 * (size_t)R.ray_depth)));
         scene->pt_slots = n_slots; scene->pt_levels = (size_t)R.ray_depth;
     }
+    const size_t group_words = 2 * (size_t)pass_groups + n_blocks_max + 1;
+    if (scene->pt_group_words < group_words) {
+        if (scene->pt_groups) (void)hipFree(scene->pt_groups);
+        scene->pt_groups = nullptr; scene->pt_group_words = 0;
+        HIP_CHECK(hipMalloc((void **)&scene->pt_groups, group_words * 4));
+        scene->pt_group_words = group_words;
+    }
+    uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + pass_groups, *d_ids = d_ofs + n_blocks_max + 1;
     dev::PtParams P{};
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
     P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL);
     P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
-    P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 64);
-    P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 128);
+    P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
+    P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);
     P.cost_t = 7; P.cost_l = 8;
     if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) { P.cost_t = a; P.cost_l = b; } }
     P.counters = scene->d_counters;
@@ -566,15 +585,19 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     P.debug = nullptr;
     if (getenv("RTAMD_DEBUG_COUNTERS")) {
         if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)1024 * 3 * sizeof(unsigned long long)));
-        HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
         if (n_blocks_max <= 1024) P.debug = scene->d_pt_debug;
     }
-    if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
+    // two phases when there is something to re-deal: enough samples, and several sub-tiles per workgroup
+    const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
+    const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
+    const uint32_t phases = two_phase ? 2u : 1u;
+    if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes * phases) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     dev::WfView W{};
     W.r0 = scene->pt_r0;
     W.stride = 4u + 2u * (uint32_t)scene->pt_levels;
-    uint32_t first = 0;
-    scene->pt_blocks = 0;
+    uint32_t first = 0, launch = 0;
+    scene->pt_blocks = 0; scene->pt_rebalance_ms = 0; scene->pt_imbalance = 0;
+    std::vector<uint32_t> cost, ofs, ids, order;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t groups = n_work - first < pass_groups ? n_work - first : pass_groups;
         W.n_slots = groups * 64u;
@@ -582,14 +605,63 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
         P.n_groups = groups;
         const uint32_t blocks = groups < n_blocks_max ? groups : n_blocks_max;
         if (blocks > scene->pt_blocks) scene->pt_blocks = blocks;
-        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * p], stream));
-        if (count) hipLaunchKernelGGL(dev::pt_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, R, W, P);
-        else hipLaunchKernelGGL(dev::pt_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, R, W, P);
-        if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * p + 1], stream));
+        for (uint32_t ph = 0; ph < phases; ph++) {
+            RenderView Rp = R;
+            Rp.sample_stop = (two_phase && ph == 0) ? phase0 : R.samples;
+            P.resume = ph;
+            P.group_cost = (two_phase && ph == 0) ? d_cost : nullptr;
+            P.group_ofs = ph ? d_ofs : nullptr;
+            P.group_ids = ph ? d_ids : nullptr;
+            if (ph == 1) { // re-deal: longest processing time first onto the least loaded workgroup (at most groups_per_block each)
+                cost.resize(groups);
+                HIP_CHECK(hipStreamSynchronize(stream));
+                const double t0 = now_ms();
+                HIP_CHECK(hipMemcpy(cost.data(), d_cost, (size_t)groups * 4, hipMemcpyDeviceToHost));
+                order.resize(groups);
+                for (uint32_t g = 0; g < groups; g++) order[g] = g;
+                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
+                std::vector<std::pair<uint64_t, uint32_t>> heap; // (load, block), min-heap
+                heap.reserve(blocks);
+                for (uint32_t b = 0; b < blocks; b++) heap.push_back({0ull, b});
+                auto cmp = [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a > b; };
+                std::make_heap(heap.begin(), heap.end(), cmp);
+                std::vector<std::vector<uint32_t>> mine(blocks);
+                uint64_t total = 0, before_max = 0;
+                { std::vector<uint64_t> rr(blocks, 0); for (uint32_t g = 0; g < groups; g++) { rr[g % blocks] += cost[g]; total += cost[g]; } for (uint64_t v : rr) before_max = v > before_max ? v : before_max; }
+                for (uint32_t g : order) {
+                    std::pop_heap(heap.begin(), heap.end(), cmp);
+                    auto &top = heap.back();
+                    mine[top.second].push_back(g);
+                    top.first += (uint64_t)cost[g] + 1u; // + 1: empty sub-tiles (padding) are spread evenly too
+                    if (mine[top.second].size() >= groups_per_block) heap.pop_back(); // full: out of the deal
+                    else std::push_heap(heap.begin(), heap.end(), cmp);
+                }
+                ofs.assign(blocks + 1, 0);
+                ids.clear();
+                for (uint32_t b = 0; b < blocks; b++) {
+                    std::sort(mine[b].begin(), mine[b].end());
+                    ofs[b] = (uint32_t)ids.size();
+                    ids.insert(ids.end(), mine[b].begin(), mine[b].end());
+                }
+                ofs[blocks] = (uint32_t)ids.size();
+                HIP_CHECK(hipMemcpyAsync(d_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, stream));
+                HIP_CHECK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, stream));
+                HIP_CHECK(hipStreamSynchronize(stream)); // the vectors are reused by the next pass
+                scene->pt_rebalance_ms += now_ms() - t0;
+                if (total) scene->pt_imbalance = (double)before_max * blocks / (double)total; // slowest workgroup / mean under the round-robin deal
+            }
+            if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
+            if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
+            if (count) hipLaunchKernelGGL(dev::pt_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
+            else hipLaunchKernelGGL(dev::pt_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
+            if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch + 1], stream));
+            launch++;
+        }
         first += groups;
     }
     HIP_CHECK(hipGetLastError());
     scene->pt_passes = passes;
+    scene->pt_launches = launch;
 }
 
 int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_t *out_rgb8, rt_stats *stats) {
@@ -632,6 +704,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         // scene.cpp:181,176 — evaluated on the host in float exactly like the reference
         R.tan_fov_x = scene->view.tan_fov_y * R.width / R.height;
         R.inv_samples = (float)(1.0 / R.samples);
+        R.sample_stop = R.samples;
         uint32_t n_work = R.n_shard_tiles * (uint32_t)((R.tile_w >> 3) * (R.tile_h >> 3));
         const int streams = p->sample_streams > 1 ? p->sample_streams : 1;
         if (p->reserved != 0) return fail(RT_ERR_INVALID_ARG, "rt_render: reserved must be 0");
@@ -680,6 +753,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 if (streams > 1) {
                     R.streams = streams; R.n_pixslots = n_work * 64u; R.seed_stride = (uint32_t)R.width * (uint32_t)R.height;
                     R.samples /= streams;                           // per stream; inv_samples stays 1 / (all samples of the pixel)
+                    R.sample_stop = R.samples;
                     const size_t need = (size_t)streams * R.n_pixslots * 3 * sizeof(float);
                     if (scene->partial_bytes < need) {
                         if (scene->d_partial) (void)hipFree(scene->d_partial);
@@ -693,7 +767,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 if (use_persistent) {
                     time_trace = stats != nullptr;
                     launch_persistent(scene, V8, R, n_work * (uint32_t)streams, stream, count, time_trace);
-                    launches = scene->pt_passes;
+                    launches = scene->pt_launches;
                 } else {
                 time_trace = stats != nullptr && wavefront_rounds(V8, R) * (size_t)wavefront_pipelines(n_work * (uint32_t)streams) <= 65536;
                 launch_wavefront(scene, V8, R, n_work * (uint32_t)streams, stream, count, time_trace);
@@ -754,7 +828,17 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 unsigned long long t0 = ~0ull, tmin = ~0ull, tmax = 0; double tsum = 0;
                 for (uint32_t b = 0; b < scene->pt_blocks; b++) if (dbg[3 * b] && dbg[3 * b] < t0) t0 = dbg[3 * b];
                 for (uint32_t b = 0; b < scene->pt_blocks; b++) { unsigned long long e = dbg[3 * b + 1] - t0; tmin = e < tmin ? e : tmin; tmax = e > tmax ? e : tmax; tsum += (double)e; }
-                fprintf(stderr, "[rtamd] persistent kernel (last pass): %u workgroups, exit times min / mean / max = %.3f / %.3f / %.3f ms after the first start; exact closest hits %llu, exact light sums %llu of %llu + %llu queries\n",
+                if (count) {
+                    const double tt = (double)(h_cnt[16] + h_cnt[17] + h_cnt[18] + h_cnt[19] + h_cnt[20]);
+                    fprintf(stderr, "[rtamd] persistent kernel, wave time by role: closest-hit walks %.1f %%, light walks %.1f %%, shading %.1f %%, exact walks %.2f %%, idle %.1f %%; "
+                                    "walker lane utilisation: closest hit %.1f of 64 (%llu wave iterations), light %.1f of 64 (%llu); %llu stints, %llu shade batches of %.1f paths\n",
+                            100 * h_cnt[16] / tt, 100 * h_cnt[17] / tt, 100 * h_cnt[18] / tt, 100 * h_cnt[19] / tt, 100 * h_cnt[20] / tt,
+                            (double)h_cnt[22] / (double)(h_cnt[21] ? h_cnt[21] : 1), h_cnt[21], (double)h_cnt[24] / (double)(h_cnt[23] ? h_cnt[23] : 1), h_cnt[23],
+                            h_cnt[25], h_cnt[26], (double)h_cnt[27] / (double)(h_cnt[26] ? h_cnt[26] : 1));
+                }
+                fprintf(stderr, "[rtamd] persistent pipeline: %u launches; re-deal of the sub-tiles took %.2f ms on the host (slowest workgroup / mean under the round-robin deal: %.3f)\n",
+                        scene->pt_launches, scene->pt_rebalance_ms, scene->pt_imbalance);
+                fprintf(stderr, "[rtamd] persistent kernel (last launch): %u workgroups, exit times min / mean / max = %.3f / %.3f / %.3f ms after the first start; exact closest hits %llu, exact light sums %llu of %llu + %llu queries\n",
                         scene->pt_blocks, tmin * 1e-5, tsum / scene->pt_blocks * 1e-5, tmax * 1e-5, h_cnt[12], h_cnt[13], h_cnt[0], h_cnt[1]);
             }
         }
@@ -790,8 +874,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->pipeline = (uint32_t)scene->pipeline;
             if (use_persistent) {
                 double sum = 0;
-                for (uint32_t pp = 0; time_trace && pp < scene->pt_passes; pp++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * pp], scene->ev_pool[2 * pp + 1])); sum += e; }
-                stats->dominant_kernel_ms = time_trace ? sum : ms; stats->dominant_kernel_launches = scene->pt_passes;
+                for (uint32_t pp = 0; time_trace && pp < scene->pt_launches; pp++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * pp], scene->ev_pool[2 * pp + 1])); sum += e; }
+                stats->dominant_kernel_ms = time_trace ? sum : ms; stats->dominant_kernel_launches = scene->pt_launches;
                 stats->exact_closest_hits = h_cnt[12]; stats->exact_light_sums = h_cnt[13];
             } else if (use_wavefront && blocks && time_trace) {
                 size_t rounds = wavefront_rounds(V8, R);

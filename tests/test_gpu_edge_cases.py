@@ -222,3 +222,34 @@ def test_more_rounds_than_the_per_launch_event_pool(rt, sphere_scene, monkeypatc
     ref, ref8, _ = oracle_lib.Hw8Oracle(sphere_scene).render(8, 8, 12000)
     assert st.launches == 1 + 2 * 72000 and st.dominant_kernel_launches == st.launches and st.dominant_kernel_ms == st.kernel_ms
     assert np.array_equal(rgb, ref, equal_nan=True) and np.array_equal(rgb8, ref8)
+
+
+def test_persistent_pipeline_phases_and_deals_do_not_change_pixels(rt, monkeypatch):
+    """The persistent pipeline renders a frame in two launches when it can re-deal the 8x8 sub-tiles between its workgroups
+    (first 1/16 of the samples with the round-robin deal, then longest-processing-time-first by the measured cost, every pixel
+    resuming from its record).  Forced here on a small frame (few workgroups, first phase of 2 samples): pixels, shards and
+    throughput mode must be what one launch gives, and that is the oracle's frame."""
+    import pin_cases
+    sd = pin_cases.random_triangle_scene(n=400, seed=33)
+    w, h, spp = 136, 88, 7
+    ref, ref8, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
+    scene = rt.Scene(sd)
+    monkeypatch.setenv("RTAMD_PT_NO_REBALANCE", "1")
+    one, one8, st1 = scene.render(w, h, spp)
+    shard1, _, _ = scene.render(w, h, spp, shard_index=1, shard_count=2, tile=16)
+    thr1, _, _ = scene.render(w, h, 12, sample_streams=3)
+    monkeypatch.delenv("RTAMD_PT_NO_REBALANCE")
+    assert st1.pipeline == rt.RT_PIPELINE_PERSISTENT and st1.launches == 1
+    assert np.array_equal(one, ref, equal_nan=True) and np.array_equal(one8, ref8)
+    for blocks, phase0 in ((8, 2), (3, 1), (16, 6)):
+        monkeypatch.setenv("RTAMD_PT_BLOCKS", str(blocks))
+        monkeypatch.setenv("RTAMD_PT_PHASE0", str(phase0))
+        two, two8, st2 = scene.render(w, h, spp)
+        assert st2.launches == 2 and st2.dominant_kernel_launches == 2
+        assert np.array_equal(two, one, equal_nan=True) and np.array_equal(two8, one8)
+        assert (st2.closest_hit_queries, st2.light_pdf_queries) == (st1.closest_hit_queries, st1.light_pdf_queries)
+        shard2, _, _ = scene.render(w, h, spp, shard_index=1, shard_count=2, tile=16)
+        assert np.array_equal(shard2, shard1, equal_nan=True)
+        thr2, _, stt = scene.render(w, h, 12, sample_streams=3)
+        assert np.array_equal(thr2, thr1, equal_nan=True)
+    scene.close()

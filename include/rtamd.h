@@ -212,6 +212,22 @@ int rt_render(rt_scene *scene, const rt_render_params *params,
 int rt_unshard(const rt_render_params *params, const void *shard_buf, size_t elem_size,
                void *full_image);
 
+/* ---- several GPUs in one process ---------------------------------------------------------------------------------------
+ * The reference shards nothing (one OpenMP loop over the pixels, hw8/src/sceneio.cpp:387-396, driven from main,
+ * hw8/src/main.cpp:7-18); pixels are independent and seeded by their global index, so the frame's 32x32 tiles are dealt
+ * round-robin to the devices, every device renders its shard from its own host thread, and ONE exchange step brings the shards
+ * to the first device (hipMemcpyPeerAsync over xGMI) where the tiles are scattered into the frame.  The result is bit-identical
+ * to the one-device render.  `devices` = HIP device indices (NULL = 0 .. n_devices-1; an index may repeat, which renders two
+ * shards on one GPU — used by the tests on a one-GPU machine).  rt_multi_render takes the params of an UNSHARDED frame
+ * (shard_count 0 or 1); out pointers are host memory, or memory on the first device with RT_FLAG_OUT_DEVICE; stats are summed
+ * over the devices except kernel_ms / dominant_kernel_ms (the slowest device: they render side by side) and total_ms (wall). */
+typedef struct rt_multi rt_multi;
+int rt_device_count(void);
+int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices, rt_multi **out);
+int rt_multi_render(rt_multi *multi, const rt_render_params *params, float *out_rgb_linear /* nullable */, uint8_t *out_rgb8 /* nullable */,
+                    rt_stats *stats /* nullable */);
+void rt_multi_destroy(rt_multi *multi);
+
 /* Scene info the host side needs after preparation. */
 typedef struct rt_scene_info {
     uint32_t n_triangles, n_lights, n_bvh_nodes, n_light_bvh_nodes;

@@ -95,7 +95,8 @@ class rt_scene_info(C.Structure):
 ABI_SYMBOLS = ["rt_abi_version", "rt_last_error", "rt_scene_create", "rt_scene_destroy", "rt_output_elems", "rt_render",
                "rt_unshard", "rt_scene_get_info", "rt_scene_get_light_order", "rt_load_gltf", "rt_load_txt",
                "rt_host_scene_set_environment", "rt_host_scene_desc", "rt_host_scene_free", "rt_write_ppm",
-               "rt_decode_png", "rt_free", "rt_host_prepare_orders"]
+               "rt_decode_png", "rt_free", "rt_host_prepare_orders", "rt_device_count", "rt_multi_create", "rt_multi_render",
+               "rt_multi_destroy"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -123,6 +124,10 @@ lib.rt_write_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
 lib.rt_decode_png.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_uint8))]
 lib.rt_free.argtypes = [C.c_void_p]
 lib.rt_free.restype = None
+lib.rt_multi_create.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+lib.rt_multi_render.argtypes = [C.c_void_p, C.POINTER(rt_render_params), C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]
+lib.rt_multi_destroy.argtypes = [C.c_void_p]
+lib.rt_multi_destroy.restype = None
 
 
 def _check(code):
@@ -285,6 +290,37 @@ def unshard(params, buf):
     full = np.zeros((params.height, params.width, 3), dtype=buf.dtype)
     _check(lib.rt_unshard(C.byref(params), buf.ctypes.data, buf.dtype.itemsize, full.ctypes.data))
     return full
+
+
+class MultiScene:
+    """One scene replica per listed HIP device (rt_multi); render() shards the frame over them and returns the whole frame."""
+
+    def __init__(self, data, devices):
+        self.data = data
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib.rt_multi_create(C.byref(data.desc), arr, len(devices), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.rt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, width, height, samples, want_float=True, want_rgb8=True, **kw):
+        p = make_params(width, height, samples, **kw)
+        p.shard_count, p.shard_index = 0, 0
+        rgb = np.zeros((height, width, 3), dtype=np.float32) if want_float else None
+        rgb8 = np.zeros((height, width, 3), dtype=np.uint8) if want_rgb8 else None
+        st = rt_stats()
+        _check(lib.rt_multi_render(self._h, C.byref(p), rgb.ctypes.data if want_float else None,
+                                   rgb8.ctypes.data if want_rgb8 else None, C.byref(st)))
+        return rgb, rgb8, st
 
 
 class Scene:

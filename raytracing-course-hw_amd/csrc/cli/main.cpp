@@ -3,7 +3,9 @@
 //   hw1-hw5 (hw1/src/main.cpp:7-14, hw1/run.sh):  rtamd_main <scene.txt> <out.ppm>
 // Which snapshot's integrator replays the scene: RTAMD_SNAPSHOT=hw8 (default for glTF) | hw7 | hw6, and for .txt scenes
 // hw1 | hw2 | hw3 (default) | hw4 | hw5 (grammar and integrator of that snapshot).
-// The host only parses, prepares and writes the PPM; the render loop runs on the GPU through the C-ABI.
+// The host only parses, prepares and writes the PPM; the render loop runs on the GPU through the C-ABI — on EVERY visible GPU
+// when there are several (rt_multi_*: tiles dealt round-robin, one exchange step to the first device; RTAMD_DEVICES=n limits
+// the count, RTAMD_DEVICES=1 forces the single-device path).
 #include "../../../include/rtamd.h"
 #include <cstdio>
 #include <cstdlib>
@@ -44,15 +46,25 @@ int main(int argc, const char *argv[]) {
         fprintf(stderr, "usage: %s <scene.gltf> <width> <height> <samples> <out.ppm> [<envmap.png>]\n       %s <scene.txt> <out.ppm>\n", argv[0], argv[0]);
         return 2;
     }
-    rt_scene *scene = nullptr;
-    if (rt_scene_create(rt_host_scene_desc(hs), &scene) != RT_OK) return die();
     std::vector<uint8_t> rgb8(rt_output_elems(&p));
     if (rgb8.empty()) { fprintf(stderr, "error: bad image size %dx%d\n", p.width, p.height); return 1; }
     rt_stats st;
-    if (rt_render(scene, &p, nullptr, rgb8.data(), &st) != RT_OK) return die();
+    int n_dev = rt_device_count();
+    if (const char *e = getenv("RTAMD_DEVICES")) { int v = atoi(e); if (v >= 1 && v < n_dev) n_dev = v; }
+    if (n_dev > 1 && p.integrator != RT_INTEGRATOR_HW1) {
+        rt_multi *multi = nullptr;
+        if (rt_multi_create(rt_host_scene_desc(hs), nullptr, n_dev, &multi) != RT_OK) return die();
+        if (rt_multi_render(multi, &p, nullptr, rgb8.data(), &st) != RT_OK) return die();
+        fprintf(stderr, "render: %d GPUs, slowest %.3f ms, %.2f Msamples/s over the whole call\n", n_dev, st.kernel_ms, st.samples / (st.total_ms * 1e3));
+        rt_multi_destroy(multi);
+    } else {
+        rt_scene *scene = nullptr;
+        if (rt_scene_create(rt_host_scene_desc(hs), &scene) != RT_OK) return die();
+        if (rt_render(scene, &p, nullptr, rgb8.data(), &st) != RT_OK) return die();
+        fprintf(stderr, "render: %.3f ms on the GPU, %.2f Msamples/s\n", st.kernel_ms, st.samples / (st.kernel_ms * 1e3));
+        rt_scene_destroy(scene);
+    }
     if (rt_write_ppm(out_path, p.width, p.height, rgb8.data()) != RT_OK) return die();
-    fprintf(stderr, "render: %.3f ms on the GPU, %.2f Msamples/s\n", st.kernel_ms, st.samples / (st.kernel_ms * 1e3));
-    rt_scene_destroy(scene);
     rt_host_scene_free(hs);
     fprintf(stderr, "FINISH\n");
     return 0;

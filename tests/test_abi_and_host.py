@@ -81,6 +81,16 @@ def test_shard_layout_roundtrip(rt):
         assert np.array_equal(acc, full)
 
 
+def test_multi_device_entry_points_fail_loudly_without_a_gpu(rt, sphere_scene):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert rt.lib.rt_device_count() == 0
+    with pytest.raises(rt.RtError) as e:
+        rt.MultiScene(sphere_scene, [0, 1])
+    assert e.value.code == rt.RT_ERR_NO_DEVICE
+
+
 def test_no_gpu_means_loud_failure_not_fallback(rt, sphere_scene):
     import torch
     if torch.cuda.is_available():

@@ -345,7 +345,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload and world == 1 and tj.get("kernel") == roofline["kernel"]:
-                    roofline["traffic"] = tj["bytes_per_launch"]
+                    roofline["traffic"] = int(tj["bytes_per_frame"] / max(1, roofline["kernel_launches_per_step"])) if "bytes_per_frame" in tj else tj["bytes_per_launch"]
                     roofline["traffic_source"] = tj.get("source", "profiles/traffic_latest.json")
             except (OSError, ValueError, KeyError):
                 pass

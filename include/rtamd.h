@@ -145,6 +145,14 @@ typedef struct rt_scene_desc {
 
 #define RT_FLAG_OUT_DEVICE 1u /* out_rgb_linear / out_rgb8 are device pointers on the scene's GPU */
 #define RT_FLAG_COUNTERS   2u /* also fill the work counters of rt_stats (slower kernel variant) */
+/* Throughput mode only (sample_streams > 1; not the reference's estimator any more, statistical parity only):
+ * RT_FLAG_SAMPLE_SEEDS     every camera sample draws from its own engine, seeded with a hash of (pixel, sample index), instead of
+ *                          continuing its stream's engine: samples of a pixel are then independent of how they are dealt to streams;
+ * RT_FLAG_RUSSIAN_ROULETTE from the third bounce on a path survives a bounce with probability q = clamp(max component of the
+ *                          bounce's throughput factor, 0.05, 1) and its factor is divided by q (the reference ends paths by depth
+ *                          and its clamp hack only, hw8/src/scene.cpp:85-87,161-163; both stay in force). */
+#define RT_FLAG_SAMPLE_SEEDS     4u
+#define RT_FLAG_RUSSIAN_ROULETTE 8u
 
 typedef struct rt_render_params {
     uint32_t struct_size; /* = sizeof(rt_render_params) */

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "librtamd.so")
 
 RT_INTEGRATOR_HW1, RT_INTEGRATOR_HW2, RT_INTEGRATOR_HW3, RT_INTEGRATOR_HW4, RT_INTEGRATOR_HW5 = 1, 2, 3, 4, 5
 RT_INTEGRATOR_HW6, RT_INTEGRATOR_HW7, RT_INTEGRATOR_HW8 = 6, 7, 8
-RT_FLAG_OUT_DEVICE, RT_FLAG_COUNTERS = 1, 2
+RT_FLAG_OUT_DEVICE, RT_FLAG_COUNTERS, RT_FLAG_SAMPLE_SEEDS, RT_FLAG_RUSSIAN_ROULETTE = 1, 2, 4, 8
 RT_PIPELINE_SINGLE, RT_PIPELINE_ROUNDS, RT_PIPELINE_PERSISTENT = 0, 1, 2
 RT_OK = 0
 RT_ERR_NO_DEVICE = -2
@@ -353,9 +353,9 @@ class Scene:
         _check(lib.rt_scene_get_light_order(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
         return out[:n]
 
-    def render(self, width, height, samples, want_float=True, want_rgb8=True, counters=False, **kw):
+    def render(self, width, height, samples, want_float=True, want_rgb8=True, counters=False, flags=0, **kw):
         """Render to host arrays. Returns (rgb float32 (H,W,3) or shard buffer, rgb8, rt_stats)."""
-        p = make_params(width, height, samples, flags=RT_FLAG_COUNTERS if counters else 0, **kw)
+        p = make_params(width, height, samples, flags=(RT_FLAG_COUNTERS if counters else 0) | flags, **kw)
         n = lib.rt_output_elems(C.byref(p))
         if n == 0:
             raise RtError(-1, "bad render parameters")

@@ -573,6 +573,7 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             } else {
                 Rng rng;
                 rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (gslot / R.n_pixslots) * R.seed_stride : 0u)); // sceneio.cpp:389-391
+                if (R.sample_seeds) wf_sample_seed(R, rng, gslot, x, y, 0u);
                 F3 o, d;
                 wf_camera_ray(S, R, rng, x, y, o, d);
                 float4 *r = wf_rec(W, slot);

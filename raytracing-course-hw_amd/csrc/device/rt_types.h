@@ -127,6 +127,9 @@ struct RenderView {
     uint32_t n_pixslots;           // pixel slots of this shard (64 per 8x8 sub-tile)
     uint32_t seed_stride;          // stream k of pixel i is seeded with i + k * seed_stride (= width * height)
     float *partial;                // [streams][n_pixslots][3]
+    uint32_t sample_seeds;         // throughput mode, RT_FLAG_SAMPLE_SEEDS: every sample seeds its own engine (hash of pixel and sample)
+    uint32_t total_samples;        // samples per pixel over all its streams
+    int32_t rr_depth;              // throughput mode, RT_FLAG_RUSSIAN_ROULETTE: first bounce index that plays roulette (0 = off)
 };
 
 } // namespace rtamd

@@ -105,6 +105,16 @@ RT_DEV void wf_flush(const Pusher &p, uint32_t *gqueue, uint32_t *gcount, uint32
     __syncthreads();
 }
 
+// RT_FLAG_SAMPLE_SEEDS: the engine of camera sample `sample_of_stream` of the slot's stream.  Consecutive minstd seeds give
+// correlated first draws, so the (pixel, sample) pair goes through a 32-bit mixer (the finalizer of MurmurHash3) first.
+RT_DEV void wf_sample_seed(const RenderView &R, Rng &rng, uint32_t gslot, int x, int y, uint32_t sample_of_stream) {
+    const uint32_t stream = R.streams > 1 ? gslot / R.n_pixslots : 0u;
+    const uint32_t global_sample = sample_of_stream * (uint32_t)(R.streams > 1 ? R.streams : 1) + stream;
+    uint32_t h = ((uint32_t)(y * R.width + x)) * R.total_samples + global_sample;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    rng_seed(rng, h);
+}
+
 RT_DEV void wf_camera_ray(const SceneView &S, const RenderView &R, Rng &rng, int x, int y, F3 &o, F3 &d) {
     float nx = (float)x + rng_u01(rng);                             // scene.cpp:172-173
     float ny = (float)y + rng_u01(rng);
@@ -137,6 +147,7 @@ RT_DEV int wf_finish_path(const SceneView &S, const RenderView &R, const WfView 
     wf_slot_to_pixel(R, slot + W.slot_base, x, y, inside, out_index);
     if (sample < (uint32_t)R.samples) {
         F3 o, d;
+        if (R.sample_seeds) wf_sample_seed(R, rng, slot + W.slot_base, x, y, sample);
         wf_camera_ray(S, R, rng, x, y, o, d);
         r[0] = make_float4(o.x, o.y, o.z, d.x);
         r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
@@ -177,6 +188,7 @@ __global__ __launch_bounds__(256) void wf_init_kernel(SceneView S, RenderView R,
             } else {
                 Rng rng;
                 rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (gslot / R.n_pixslots) * R.seed_stride : 0u)); // sceneio.cpp:389-391
+                if (R.sample_seeds) wf_sample_seed(R, rng, gslot, x, y, 0u);
                 F3 o, d;
                 wf_camera_ray(S, R, rng, x, y, o, d);
                 float4 *r = wf_rec(W, slot);
@@ -644,8 +656,21 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
             levels = depth;
             if (!clamp) { e[1] = make_float4(mult.x, mult.y, mult.z, e1.w); tail = f3(0.f, 0.f, 0.f); levels = depth + 1; }
         } else {
+            bool survives = true;
+            if (R.rr_depth > 0 && depth + 1 >= R.rr_depth) {
+                // Russian roulette (throughput mode only): the bounce continues with probability q and carries mult / q, else the
+                // path returns its emission as if the inner call were 0 (the traced hit is dropped like a clamped one).
+                const float q = fminf(1.f, fmaxf(0.05f, fmaxf(mult.x, fmaxf(mult.y, mult.z))));
+                survives = rng_u01(rng) < q;
+                mult = (1.f / q) * mult;
+            }
             e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
-            depth++;
+            if (survives) depth++;
+            else {
+                if (counters) atomicAdd(&counters[10], 1ull);
+                if (discarded) *discarded = true;
+                ended = true; tail = f3(0.f, 0.f, 0.f); levels = depth + 1;
+            }
         }
     }
     if (!ended) {

@@ -708,6 +708,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         uint32_t n_work = R.n_shard_tiles * (uint32_t)((R.tile_w >> 3) * (R.tile_h >> 3));
         const int streams = p->sample_streams > 1 ? p->sample_streams : 1;
         if (p->reserved != 0) return fail(RT_ERR_INVALID_ARG, "rt_render: reserved must be 0");
+        if ((p->flags & (RT_FLAG_SAMPLE_SEEDS | RT_FLAG_RUSSIAN_ROULETTE)) && streams <= 1)
+            return fail(RT_ERR_INVALID_ARG, "rt_render: RT_FLAG_SAMPLE_SEEDS / RT_FLAG_RUSSIAN_ROULETTE change the estimator and belong to throughput mode (sample_streams > 1)");
         if (streams > 1) { // throughput mode (include/rtamd.h: sample_streams)
             if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW7) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 is implemented for RT_INTEGRATOR_HW8 / HW7 only");
             if (streams > 256 || R.samples % streams != 0) return fail(RT_ERR_INVALID_ARG, "rt_render: samples must be a multiple of sample_streams (at most 256 streams)");
@@ -752,6 +754,9 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             if (use_wavefront) {
                 if (streams > 1) {
                     R.streams = streams; R.n_pixslots = n_work * 64u; R.seed_stride = (uint32_t)R.width * (uint32_t)R.height;
+                    R.total_samples = (uint32_t)R.samples;
+                    R.sample_seeds = (p->flags & RT_FLAG_SAMPLE_SEEDS) ? 1u : 0u;
+                    R.rr_depth = (p->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 2 : 0;
                     R.samples /= streams;                           // per stream; inv_samples stays 1 / (all samples of the pixel)
                     R.sample_stop = R.samples;
                     const size_t need = (size_t)streams * R.n_pixslots * 3 * sizeof(float);

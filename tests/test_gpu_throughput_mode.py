@@ -87,3 +87,34 @@ def test_throughput_mode_rejects_what_it_cannot_do(rt, sphere_scene):
     with pytest.raises(rt.RtError):
         s6.render(16, 16, 4, integrator=rt.RT_INTEGRATOR_HW6, sample_streams=2)
     s6.close()
+
+
+def test_russian_roulette_and_per_sample_seeds(rt, sphere_scene):
+    """SURVEY 8(f)3, the non-replay estimator options of throughput mode.  RT_FLAG_SAMPLE_SEEDS: every camera sample has its own
+    engine seeded from (pixel, sample index), so the image does not depend on how the samples are dealt to streams (up to the
+    order of the float additions).  RT_FLAG_RUSSIAN_ROULETTE: paths die early with probability 1 - q and survivors are weighted
+    1 / q — fewer queries, the same expectation: against a 2048-spp replay render the bias stays within 4 standard errors."""
+    scene = rt.Scene(sphere_scene)
+    w, h = 96, 64
+    conv, _, _ = scene.render(w, h, 2048, want_rgb8=False)
+    thr, _, st_thr = scene.render(w, h, 64, want_rgb8=False, sample_streams=8)
+    s4, _, _ = scene.render(w, h, 64, want_rgb8=False, sample_streams=4, flags=rt.RT_FLAG_SAMPLE_SEEDS)
+    s8, _, _ = scene.render(w, h, 64, want_rgb8=False, sample_streams=8, flags=rt.RT_FLAG_SAMPLE_SEEDS)
+    rr, _, st_rr = scene.render(w, h, 64, want_rgb8=False, sample_streams=8, flags=rt.RT_FLAG_SAMPLE_SEEDS | rt.RT_FLAG_RUSSIAN_ROULETTE)
+    with pytest.raises(rt.RtError):
+        scene.render(w, h, 64, flags=rt.RT_FLAG_RUSSIAN_ROULETTE)      # replay mode keeps the reference's estimator
+    scene.close()
+    ok = np.isfinite(conv).all(axis=2) & np.isfinite(thr).all(axis=2) & np.isfinite(s8).all(axis=2) & np.isfinite(rr).all(axis=2) & np.isfinite(s4).all(axis=2)
+    assert ok.mean() > 0.99
+    assert np.allclose(s4[ok], s8[ok], rtol=2e-5, atol=2e-6) and not np.array_equal(s8, thr)
+    def stats(img):
+        e = (img - conv)[ok].astype(np.float64)
+        return np.sqrt((e ** 2).mean()), e.mean(), e.std() / np.sqrt(e.size)
+    rmse_t, _, _ = stats(thr)
+    rmse_s, bias_s, se_s = stats(s8)
+    rmse_r, bias_r, se_r = stats(rr)
+    print(f"rmse vs 2048 spp: streams {rmse_t:.4f}, per-sample seeds {rmse_s:.4f} (bias {bias_s:.2e}, se {se_s:.2e}), + roulette {rmse_r:.4f} (bias {bias_r:.2e}, se {se_r:.2e}); "
+          f"closest-hit queries {st_thr.closest_hit_queries} -> {st_rr.closest_hit_queries}")
+    assert 0.75 < rmse_s / rmse_t < 1.33 and abs(bias_s) < 4 * se_s + 1e-6
+    assert 0.75 < rmse_r / rmse_t < 2.0 and abs(bias_r) < 4 * se_r + 1e-6
+    assert st_rr.closest_hit_queries < st_thr.closest_hit_queries

@@ -38,7 +38,16 @@ namespace dev {
 
 #define PT_THREADS 1024
 #define PT_WAVES 16
+// Experiment: -DPT_TREELET=511 keeps the top 511 nodes of the scene tree (breadth-first, 32,704 B) in LDS; the
+// bitmaps then hold 8,192 paths per workgroup instead of 32,768 so that stacks + bitmaps + treelet fill the 160 KB exactly.
+#ifndef PT_TREELET
+#define PT_TREELET 0
+#endif
+#if PT_TREELET
+#define PT_MAX_PATHS 8192
+#else
 #define PT_MAX_PATHS 32768            // paths per workgroup (bitmap capacity in LDS)
+#endif
 #define PT_NW (PT_MAX_PATHS / 32)
 #define PT_BIT_T 1u                   // pending: closest-hit walk outstanding
 #define PT_BIT_L 2u                   // pending: light-pdf sum outstanding
@@ -61,6 +70,9 @@ struct PtShared {
     uint32_t groups[PT_MAX_PATHS / 64];       // local 64-slot group -> group of the pass (8x8 sub-tile)
     uint32_t cost[PT_MAX_PATHS / 64];         // shaded hits per local group in this launch: the load measure the frame is re-dealt by
     int cnt[16];
+#if PT_TREELET
+    float4 treelet[PT_TREELET][4];
+#endif
 };
 
 struct PtParams {
@@ -74,6 +86,7 @@ struct PtParams {
     int refill, leaf_batch;           // as in rt_wavefront.h (leaf_batch = batch | share << 16)
     int shade_thr0, shade_thr_step;   // wave w stops refilling its walkers when need_shade holds >= thr0 + w * step paths
     int cost_t, cost_l;               // relative cost of a closest-hit / light query (walker split)
+    int prio;                         // experiment: 1 = walker stints run at raised wave priority (s_setprio 2), 2 = shader batches do
     unsigned long long deadline_ticks; // 100 MHz ticks a wave may spend in this launch before it gives up (error)
     unsigned long long *counters;     // [0] closest-hit queries, [1] light queries, [2] node visits, [3] triangle tests, [10] discarded speculative hits, [12] exact closest hits, [13] exact light sums, [14] waves that gave up waiting (error)
     unsigned long long *debug;        // nullable: per workgroup {start time, exit time of its last wave (100 MHz ticks), paths}
@@ -347,7 +360,11 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) { prof.trace_iters++; prof.trace_lane_iters += __popcll(__ballot(inner)); }
             if (inner) {
+#if PT_TREELET
+                const float4 *q = cur < (uint32_t)PT_TREELET ? (const float4 *)sh.treelet[cur] : reinterpret_cast<const float4 *>(S.nodes + cur);
+#else
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
+#endif
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
@@ -552,6 +569,10 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
     for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
     for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
     if (tid < 16u) sh.cnt[tid] = 0;
+#if PT_TREELET
+    for (uint32_t i = tid; i < (uint32_t)PT_TREELET * 4u; i += PT_THREADS)
+        sh.treelet[i >> 2][i & 3u] = (i >> 2) < S.n_nodes ? reinterpret_cast<const float4 *>(S.nodes + (i >> 2))[i & 3u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     __syncthreads();
     for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) {
         const uint32_t l = base + tid;
@@ -652,6 +673,7 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
         if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
             const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
             int todo = 0;
             bool discarded = false;
             if (got != PT_NONE) todo = pt_shade_item(S, R, W, pt_slot(sh, got), discarded);
@@ -666,6 +688,7 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == WF_PARKED)); // finished, or parked for the next phase
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;
+            if (P.prio == 2) __builtin_amdgcn_s_setprio(0);
             if (COUNT) { prof.shade_batches++; prof.shade_items += __popcll(__ballot(got != PT_NONE)); }
             lap(prof.t_shade);
             continue;
@@ -673,6 +696,7 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
         if (nt + nl > 0) {
             // walkers: the kind whose backlog per walking wave (weighted by the cost of a query) is larger
             const long long wt = (long long)nt * P.cost_t * (pt_count(&sh.cnt[PT_W_LIGHT]) + 1), wl = (long long)nl * P.cost_l * (pt_count(&sh.cnt[PT_W_TRACE]) + 1);
+            if (P.prio == 1) __builtin_amdgcn_s_setprio(2);
             if (nl == 0 || (nt > 0 && wt >= wl)) {
                 if (lane == 0) atomicAdd(&sh.cnt[PT_W_TRACE], 1);
                 pt_trace_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_closest, n_nodes, n_tris, prof);
@@ -684,6 +708,7 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
                 if (lane == 0) atomicSub(&sh.cnt[PT_W_LIGHT], 1);
                 lap(prof.t_light);
             }
+            if (P.prio == 1) __builtin_amdgcn_s_setprio(0);
             idle_spins = 0;
             if (COUNT) prof.stints++;
             continue;

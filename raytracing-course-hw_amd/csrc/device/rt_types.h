@@ -93,6 +93,7 @@ struct SceneView {
     float box_c2;
     uint32_t exact_boxes;          // 0 = accept every hit of the conservative walk (the round pipeline's behaviour)
     uint32_t n_tris, n_lights, n_components;
+    uint32_t n_nodes;              // inner nodes of the scene BVH (`nodes`)
     // 1 when every material has 0 <= metallicFactor <= 1 and a non-negative base colour: then the BRDF is >= 0,
     // the throughput of the deepest level is in [0, inf] or NaN, and that level returns exactly its emission
     // (emission + mult*0, or emission via the clamp) — the wavefront path then skips its BRDF/pdf work.

@@ -204,6 +204,34 @@ void encode_ref_tree(const std::vector<RefNode> &ref, std::vector<GpuRefNode> &o
     }
 }
 
+// Renumber the inner nodes so that the first `top` of them are the top of the tree in breadth-first order (root = 0 stays):
+// the persistent kernel's LDS treelet experiment (device/rt_persistent.h, PT_TREELET) keeps nodes [0, top) in LDS.  Any numbering
+// is valid for every kernel (children are explicit references); the rest keep their depth-first order.
+void bfs_top_first(std::vector<GpuNode> &nodes, uint32_t top) {
+    const uint32_t n = (uint32_t)nodes.size();
+    if (n <= 1 || top <= 1) return;
+    std::vector<uint32_t> order; // new index -> old index
+    order.reserve(n);
+    std::vector<uint8_t> taken(n, 0);
+    order.push_back(0); taken[0] = 1;
+    for (size_t head = 0; head < order.size() && order.size() < top; head++) {
+        const GpuNode &g = nodes[order[head]];
+        for (int32_t c : {g.child0, g.child1})
+            if (c >= 0 && (uint32_t)c < n && !taken[c] && order.size() < top) { order.push_back((uint32_t)c); taken[c] = 1; }
+    }
+    for (uint32_t i = 0; i < n; i++) if (!taken[i]) order.push_back(i);
+    std::vector<uint32_t> new_of(n);
+    for (uint32_t i = 0; i < n; i++) new_of[order[i]] = i;
+    std::vector<GpuNode> out(n);
+    for (uint32_t i = 0; i < n; i++) {
+        GpuNode g = nodes[order[i]];
+        if (g.child0 >= 0) g.child0 = (int32_t)new_of[g.child0];
+        if (g.child1 >= 0) g.child1 = (int32_t)new_of[g.child1];
+        out[i] = g;
+    }
+    nodes.swap(out);
+}
+
 struct V3 { float x, y, z; };
 inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 crossr(V3 a, V3 o) { return {a.z * o.y - a.y * o.z, a.x * o.z - a.z * o.x, a.y * o.x - a.x * o.y}; } // vec3.h:57-59
@@ -256,6 +284,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     out.n_ref_nodes = (uint32_t)scene_builder.nodes.size();
     std::vector<uint32_t> scene_leaf_last, light_leaf_last;
     encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
+    bfs_top_first(out.nodes, 512);
     encode_ref_tree(scene_builder.nodes, out.ref_nodes);
 
     // ---- 2. light order ---------------------------------------------------------------------------

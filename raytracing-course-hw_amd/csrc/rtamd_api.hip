@@ -297,6 +297,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         std::vector<float> lut(P.srgb_lut, P.srgb_lut + 256);
         V.srgb_lut = keep(upload(lut, bytes));
         V.n_tris = desc->n_triangles;
+        V.n_nodes = (uint32_t)P.nodes.size();
         V.n_lights = (uint32_t)P.lights.size();
         V.n_components = P.lights.empty() ? 2u : 3u; // scene.cpp:65-74
         V.last_level_emission_only = 1;
@@ -580,6 +581,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);
     P.cost_t = 7; P.cost_l = 8;
     if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) { P.cost_t = a; P.cost_l = b; } }
+    P.prio = getenv("RTAMD_PT_PRIO") ? atoi(getenv("RTAMD_PT_PRIO")) : 0;
     P.counters = scene->d_counters;
     P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
     P.debug = nullptr;

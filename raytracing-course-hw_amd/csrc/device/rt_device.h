@@ -216,30 +216,6 @@ RT_DEV bool slab_test(float4 lo, float4 hi, const RayInv &r, float tbest, float 
     return (tmin <= tmax) & (tmax >= 0.f) & (tmin <= tbest);
 }
 
-// The same test with one fused multiply-add per plane: t = lo * inv + (-o * inv).  The rounding of the precomputed -o * inv
-// adds an ABSOLUTE error of up to 2^-24 |o_k inv_k| per axis, covered by the per-ray pad `e` = 2^-23 max_k |o_k inv_k|
-// on top of the relative widening.  Half the multiplies and subtractions of slab_test per box.
-struct RayFma { F3 inv, noi; float e; };
-RT_DEV RayFma make_ray_fma(F3 o, F3 d) {
-    RayInv r = make_ray_inv(o, d);
-    RayFma f;
-    f.inv = r.inv;
-    f.noi = f3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
-    f.e = 1.1920929e-07f * fmaxf(fmaxf(fabsf(f.noi.x), fabsf(f.noi.y)), fabsf(f.noi.z));
-    return f;
-}
-RT_DEV bool slab_test_fma(float4 lo, float4 hi, const RayFma &r, float tbest, float &tnear) {
-    float t0x = fmaf(lo.x, r.inv.x, r.noi.x), t1x = fmaf(hi.x, r.inv.x, r.noi.x);
-    float t0y = fmaf(lo.y, r.inv.y, r.noi.y), t1y = fmaf(hi.y, r.inv.y, r.noi.y);
-    float t0z = fmaf(lo.z, r.inv.z, r.noi.z), t1z = fmaf(hi.z, r.inv.z, r.noi.z);
-    float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-    float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-    tmin = fmaf(-fabsf(tmin), 4.8e-7f, tmin) - r.e;
-    tmax = fmaf(fabsf(tmax), 4.8e-7f, tmax) + r.e;
-    tnear = tmin;
-    return (tmin <= tmax) & (tmax >= 0.f) & (tmin <= tbest);
-}
-
 #define RT_LEAF_BIT 0x80000000u
 #define RT_EMPTY_LEAF 0xFFFFFFFFu
 #define RT_STACK_SIZE 64

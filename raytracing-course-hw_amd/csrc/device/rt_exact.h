@@ -1,0 +1,162 @@
+// Reference-exact box decisions, shared by the persistent pipeline (rt_persistent.h) and the round pipeline (rt_wavefront.h).
+//
+// The walkers prune with a cheap conservative test on padded boxes, so they find a superset of the triangles the reference's own
+// slab test (hw8/src/primitives.cpp:29-53,163-165: six IEEE divisions on the re-centred, unpadded box) lets through.  A hit is
+// accepted as it stands when the hit point lies robustly inside its triangle's box (pt_box_robust: then every ancestor box
+// passes the reference's test whatever the rounding) and no second triangle was hit within a few ulp of it; the rare others are
+// walked again with the reference's arithmetic over the reference's own trees (ref_closest_hit, ref_light_pdf_sum).
+#pragma once
+#include "rt_kernels_hw8.h"
+
+namespace rtamd {
+namespace dev {
+
+#define PT_SHADE_EXACT 4              // action code of pt_shade_item: the hit needs the exact walk before it is shaded
+// hit word of a path record: 0xFFFFFFFF = miss, else figure index | flags; packed word: see rt_wavefront.h
+#define WF_MISS 0xFFFFFFFFu
+#define WF_INSIDE_BIT 0x40000000u
+#define WF_NEAR_TIE_BIT 0x80000000u   // another triangle was hit within a few ulp of the best t (never set on WF_MISS)
+#define WF_INDEX_MASK 0x3FFFFFFFu
+#define WF_SAMPLE_MASK 0x01FFFFFFu    // 25 bits of sample index in the packed word
+#define WF_VERIFIED_BIT 0x80000000u   // packed word: the hit in q2 comes from the reference-exact walk
+
+// AABB::intersect -> intersectBoxAndRay(0.5 * (max - min), ray - 0.5 * (min + max), false), primitives.cpp:163-165,29-53.
+RT_DEV bool ref_box_test(F3 mn, F3 mx, F3 o, F3 d, float &t, bool &inside) {
+    const F3 s = 0.5f * (mx - mn);
+    const F3 oc = o - 0.5f * (mn + mx);
+    const F3 a = neg(s) - oc, b = s - oc;
+    const float a1x = a.x / d.x, a1y = a.y / d.y, a1z = a.z / d.z;
+    const float a2x = b.x / d.x, a2y = b.y / d.y, a2z = b.z / d.z;
+    const float t1x = smin(a1x, a2x), t2x = smax(a1x, a2x);
+    const float t1y = smin(a1y, a2y), t2y = smax(a1y, a2y);
+    const float t1z = smin(a1z, a2z), t2z = smax(a1z, a2z);
+    const float t1 = smax(smax(t1x, t1y), t1z);
+    const float t2 = smin(smin(t2x, t2y), t2z);
+    if (t1 > t2 || t2 < 0) return false;
+    if (t1 < 0) { inside = true; t = t2; }
+    else { inside = false; t = t1; }
+    return true;
+}
+
+struct RefNodeView { F3 mn, mx; uint32_t left, right, first, last; };
+RT_DEV RefNodeView load_ref_node(const GpuRefNode *p) {
+    const float4 *q = reinterpret_cast<const float4 *>(p);
+    const float4 a = q[0], b = q[1], c = q[2];
+    RefNodeView n;
+    n.mn = f3(a.x, a.y, a.z); n.left = __float_as_uint(a.w);
+    n.mx = f3(b.x, b.y, b.z); n.right = __float_as_uint(b.w);
+    n.first = __float_as_uint(c.x); n.last = __float_as_uint(c.y);
+    return n;
+}
+
+// BVH::intersect_ (bvh.h:111-142) as an iterative depth-first walk, left child first: the recursion's `curBest` is the running
+// best of all hits found so far, a leaf keeps its first triangle on equal t, and a later subtree replaces the best only when
+// strictly closer — so one running best with strict '<' reproduces the result.  `stack` holds up to RT_STACK_SIZE node indices.
+RT_DEV void ref_closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, float &best_t, float &best_u, float &best_v, uint32_t &hit) {
+    best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; hit = WF_MISS;
+    if (S.n_tris == 0) return;
+    int sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        const RefNodeView n = load_ref_node(S.ref_nodes + cur);
+        float tb; bool inside;
+        if (ref_box_test(n.mn, n.mx, o, d, tb, inside) && !(hit != WF_MISS && best_t < tb && !inside)) {
+            if (n.left == 0) {
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    const TriIsect T = load_isect(S.tri_isect + i);
+                    float t, u, v; bool in;
+                    if (tri_test(T, o, d, t, u, v, in) && (hit == WF_MISS || t < best_t)) {
+                        best_t = t; best_u = u; best_v = v; hit = i | (in ? WF_INSIDE_BIT : 0u);
+                    }
+                }
+            } else if (sp < RT_STACK_SIZE) { stack[sp++] = n.right; cur = n.left; continue; }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+
+// FiguresMix::getTotalPdf (distributions.h:148-165) over the reference light tree with the reference's box test and its
+// association of the additions (TODO / ADD frames as in light_pdf_sum, rt_device.h).
+RT_DEV float ref_light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack) {
+    int sp = 0;
+    unsigned long long addmask = 0;
+    uint32_t cur = 0;
+    bool descending = true;
+    float v = 0.f;
+    for (;;) {
+        if (descending) {
+            const RefNodeView n = load_ref_node(S.ref_light_nodes + cur);
+            float tb; bool inside;
+            if (!ref_box_test(n.mn, n.mx, x, d, tb, inside)) { v = 0.f; descending = false; }
+            else if (n.left == 0) {
+                float result = 0.f;
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    bool last;
+                    result += light_pdf_one(S.lights + i, x, d, last, S.hw7 != 0);
+                }
+                v = result;
+                descending = false;
+            } else if (sp < RT_STACK_SIZE) { addmask &= ~(1ull << sp); stack[sp++] = n.right; cur = n.left; }
+            else { v = 0.f; descending = false; } // deeper than the host admits (checked there)
+        } else {
+            if (sp == 0) break;
+            --sp;
+            const uint32_t f = stack[sp];
+            if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;                  // left total + right total
+            else { addmask |= 1ull << sp; stack[sp++] = __float_as_uint(v); cur = f; descending = true; }
+        }
+    }
+    return v;
+}
+
+// Is the point P = o + t d, hit on a triangle whose box is [lo, hi], robustly inside that box — so robustly that the reference's
+// slab test accepts this box and every box containing it whatever the rounding?  The reference computes per axis the slab
+// interval [ta_j, tb_j] in t (monotonic: never inverted on one axis) and accepts when max_j ta_j <= min_k tb_k and that
+// minimum is >= 0.  With a_j = t - ta_j, b_k = tb_k - t (exact, >= 0 for a point inside) the computed values are off by at
+// most ~2^-23 |t-ish| + 2^-24 |o - centre|_j / |d_j| each, so for every pair of different axes
+//     a_j + b_k >= c1 t + c2 (1/|d_j| + 1/|d_k|),   c1 = 2^-19,  c2 = 2^-20 max|coordinate|   (4x the bound)
+// is sufficient, and t + b_k >= c1 t keeps the exit in front of the origin.  Boxes only grow towards the root, which only
+// increases a_j and b_k.  A flat box (a_j = b_j = 0 on its axis) passes as long as the other axes have room.
+RT_DEV bool pt_box_robust(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
+    const float ix = 1.0f / fmaxf(fabsf(d.x), 1e-30f), iy = 1.0f / fmaxf(fabsf(d.y), 1e-30f), iz = 1.0f / fmaxf(fabsf(d.z), 1e-30f);
+    const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
+    const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
+    const float inz = d.z > 0 ? P.z - lo.z : hi.z - P.z, outz = d.z > 0 ? hi.z - P.z : P.z - lo.z;
+    const float ax = (inx - c2) * ix, ay = (iny - c2) * iy, az = (inz - c2) * iz;
+    const float bx = (outx - c2) * ix, by = (outy - c2) * iy, bz = (outz - c2) * iz;
+    const float need = 1.9073486328125e-06f * t;
+    const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
+    const float exit_ = t + fminf(fminf(bx, by), bz);
+    return worst >= need && exit_ >= need; // NaN compares false: not robust
+}
+
+// light_pdf_one (rt_device.h) that also says whether the hit is robust against the reference's box tests (pt_box_robust on
+// the light triangle's own box: a, a + b, a + c).
+RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d, bool &last, bool &robust) {
+    TriIsect T = load_isect(&L->isect);
+    last = T.pad != 0;
+    robust = true;
+    float t, u, v; bool inside;
+    if (!tri_test(T, x, d, t, u, v, inside)) return 0.f;
+    const float4 *q = reinterpret_cast<const float4 *>(L) + 3;
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    float point_prob = q1.z;
+    F3 n3 = f3(q1.w, q2.x, q2.y), dn1 = f3(q2.z, q2.w, q3.x), dn2 = f3(q3.y, q3.z, q3.w);
+    F3 sn = n3 + u * dn1 + v * dn2;           // primitives.cpp:110
+    sn = normalize(sn);                        // :117
+    if (inside) sn = neg(sn);                  // :118-119
+    if (S.hw7) { F3 n = f3(T.nx, T.ny, T.nz); sn = normalize(inside ? neg(n) : n); }
+    F3 y = x + t * d;                          // distributions.h:144
+    if (S.exact_boxes) {
+        const F3 a = f3(T.ax, T.ay, T.az), pb = a + f3(q0.x, q0.y, q0.z), pc = a + f3(q0.w, q1.x, q1.y);
+        const F3 lo = f3(fminf(a.x, fminf(pb.x, pc.x)), fminf(a.y, fminf(pb.y, pc.y)), fminf(a.z, fminf(pb.z, pc.z)));
+        const F3 hi = f3(fmaxf(a.x, fmaxf(pb.x, pc.x)), fmaxf(a.y, fmaxf(pb.y, pc.y)), fmaxf(a.z, fmaxf(pb.z, pc.z)));
+        robust = pt_box_robust(lo, hi, y, d, t, S.box_c2);
+    }
+    return point_prob * len2(x - y) / fabsf(dot(d, sn)); // :68-70 (pdfOne, shading normal in hw8)
+}
+
+
+} // namespace dev
+} // namespace rtamd

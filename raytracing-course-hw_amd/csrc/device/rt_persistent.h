@@ -61,7 +61,6 @@ namespace dev {
 #define PT_N_LIVE 5                   // cnt only: pixels of this workgroup not finished yet
 #define PT_W_TRACE 6                  // cnt only: waves currently walking closest hits / light sums
 #define PT_W_LIGHT 7
-#define PT_SHADE_EXACT 4              // wf-style action code of pt_shade_item: the hit needs the exact walk before it is shaded
 
 struct PtShared {
     uint32_t stack[PT_WAVES][WF_STACK][64];   // per-lane traversal stack columns, one area per wave
@@ -173,144 +172,6 @@ RT_DEV void pt_complete(PtShared &sh, uint32_t l, uint32_t bit, bool doit) {
     pt_push(sh, PT_Q_SHADE, l, ready);
 }
 
-// ---- reference-exact walks (the `exact` role) --------------------------------------------------------------------------
-// AABB::intersect -> intersectBoxAndRay(0.5 * (max - min), ray - 0.5 * (min + max), false), primitives.cpp:163-165,29-53.
-RT_DEV bool ref_box_test(F3 mn, F3 mx, F3 o, F3 d, float &t, bool &inside) {
-    const F3 s = 0.5f * (mx - mn);
-    const F3 oc = o - 0.5f * (mn + mx);
-    const F3 a = neg(s) - oc, b = s - oc;
-    const float a1x = a.x / d.x, a1y = a.y / d.y, a1z = a.z / d.z;
-    const float a2x = b.x / d.x, a2y = b.y / d.y, a2z = b.z / d.z;
-    const float t1x = smin(a1x, a2x), t2x = smax(a1x, a2x);
-    const float t1y = smin(a1y, a2y), t2y = smax(a1y, a2y);
-    const float t1z = smin(a1z, a2z), t2z = smax(a1z, a2z);
-    const float t1 = smax(smax(t1x, t1y), t1z);
-    const float t2 = smin(smin(t2x, t2y), t2z);
-    if (t1 > t2 || t2 < 0) return false;
-    if (t1 < 0) { inside = true; t = t2; }
-    else { inside = false; t = t1; }
-    return true;
-}
-
-struct RefNodeView { F3 mn, mx; uint32_t left, right, first, last; };
-RT_DEV RefNodeView load_ref_node(const GpuRefNode *p) {
-    const float4 *q = reinterpret_cast<const float4 *>(p);
-    const float4 a = q[0], b = q[1], c = q[2];
-    RefNodeView n;
-    n.mn = f3(a.x, a.y, a.z); n.left = __float_as_uint(a.w);
-    n.mx = f3(b.x, b.y, b.z); n.right = __float_as_uint(b.w);
-    n.first = __float_as_uint(c.x); n.last = __float_as_uint(c.y);
-    return n;
-}
-
-// BVH::intersect_ (bvh.h:111-142) as an iterative depth-first walk, left child first: the recursion's `curBest` is the running
-// best of all hits found so far, a leaf keeps its first triangle on equal t, and a later subtree replaces the best only when
-// strictly closer — so one running best with strict '<' reproduces the result.  `stack` holds up to RT_STACK_SIZE node indices.
-RT_DEV void ref_closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, float &best_t, float &best_u, float &best_v, uint32_t &hit) {
-    best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; hit = WF_MISS;
-    if (S.n_tris == 0) return;
-    int sp = 0;
-    uint32_t cur = 0;
-    for (;;) {
-        const RefNodeView n = load_ref_node(S.ref_nodes + cur);
-        float tb; bool inside;
-        if (ref_box_test(n.mn, n.mx, o, d, tb, inside) && !(hit != WF_MISS && best_t < tb && !inside)) {
-            if (n.left == 0) {
-                for (uint32_t i = n.first; i < n.last; i++) {
-                    const TriIsect T = load_isect(S.tri_isect + i);
-                    float t, u, v; bool in;
-                    if (tri_test(T, o, d, t, u, v, in) && (hit == WF_MISS || t < best_t)) {
-                        best_t = t; best_u = u; best_v = v; hit = i | (in ? WF_INSIDE_BIT : 0u);
-                    }
-                }
-            } else if (sp < RT_STACK_SIZE) { stack[sp++] = n.right; cur = n.left; continue; }
-        }
-        if (sp == 0) break;
-        cur = stack[--sp];
-    }
-}
-
-// FiguresMix::getTotalPdf (distributions.h:148-165) over the reference light tree with the reference's box test and its
-// association of the additions (TODO / ADD frames as in light_pdf_sum, rt_device.h).
-RT_DEV float ref_light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack) {
-    int sp = 0;
-    unsigned long long addmask = 0;
-    uint32_t cur = 0;
-    bool descending = true;
-    float v = 0.f;
-    for (;;) {
-        if (descending) {
-            const RefNodeView n = load_ref_node(S.ref_light_nodes + cur);
-            float tb; bool inside;
-            if (!ref_box_test(n.mn, n.mx, x, d, tb, inside)) { v = 0.f; descending = false; }
-            else if (n.left == 0) {
-                float result = 0.f;
-                for (uint32_t i = n.first; i < n.last; i++) {
-                    bool last;
-                    result += light_pdf_one(S.lights + i, x, d, last, S.hw7 != 0);
-                }
-                v = result;
-                descending = false;
-            } else if (sp < RT_STACK_SIZE) { addmask &= ~(1ull << sp); stack[sp++] = n.right; cur = n.left; }
-            else { v = 0.f; descending = false; } // deeper than the host admits (checked there)
-        } else {
-            if (sp == 0) break;
-            --sp;
-            const uint32_t f = stack[sp];
-            if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;                  // left total + right total
-            else { addmask |= 1ull << sp; stack[sp++] = __float_as_uint(v); cur = f; descending = true; }
-        }
-    }
-    return v;
-}
-
-// Is the point P = o + t d, hit on a triangle whose box is [lo, hi], robustly inside that box — so robustly that the reference's
-// slab test accepts this box and every box containing it whatever the rounding?  The reference computes per axis the slab
-// interval [ta_j, tb_j] in t (monotonic: never inverted on one axis) and accepts when max_j ta_j <= min_k tb_k and that
-// minimum is >= 0.  With a_j = t - ta_j, b_k = tb_k - t (exact, >= 0 for a point inside) the computed values are off by at
-// most ~2^-23 |t-ish| + 2^-24 |o - centre|_j / |d_j| each, so for every pair of different axes
-//     a_j + b_k >= c1 t + c2 (1/|d_j| + 1/|d_k|),   c1 = 2^-19,  c2 = 2^-20 max|coordinate|   (4x the bound)
-// is sufficient, and t + b_k >= c1 t keeps the exit in front of the origin.  Boxes only grow towards the root, which only
-// increases a_j and b_k.  A flat box (a_j = b_j = 0 on its axis) passes as long as the other axes have room.
-RT_DEV bool pt_box_robust(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
-    const float ix = 1.0f / fmaxf(fabsf(d.x), 1e-30f), iy = 1.0f / fmaxf(fabsf(d.y), 1e-30f), iz = 1.0f / fmaxf(fabsf(d.z), 1e-30f);
-    const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
-    const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
-    const float inz = d.z > 0 ? P.z - lo.z : hi.z - P.z, outz = d.z > 0 ? hi.z - P.z : P.z - lo.z;
-    const float ax = (inx - c2) * ix, ay = (iny - c2) * iy, az = (inz - c2) * iz;
-    const float bx = (outx - c2) * ix, by = (outy - c2) * iy, bz = (outz - c2) * iz;
-    const float need = 1.9073486328125e-06f * t;
-    const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
-    const float exit_ = t + fminf(fminf(bx, by), bz);
-    return worst >= need && exit_ >= need; // NaN compares false: not robust
-}
-
-// light_pdf_one (rt_device.h) that also says whether the hit is robust against the reference's box tests (pt_box_robust on
-// the light triangle's own box: a, a + b, a + c).
-RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d, bool &last, bool &robust) {
-    TriIsect T = load_isect(&L->isect);
-    last = T.pad != 0;
-    robust = true;
-    float t, u, v; bool inside;
-    if (!tri_test(T, x, d, t, u, v, inside)) return 0.f;
-    const float4 *q = reinterpret_cast<const float4 *>(L) + 3;
-    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    float point_prob = q1.z;
-    F3 n3 = f3(q1.w, q2.x, q2.y), dn1 = f3(q2.z, q2.w, q3.x), dn2 = f3(q3.y, q3.z, q3.w);
-    F3 sn = n3 + u * dn1 + v * dn2;           // primitives.cpp:110
-    sn = normalize(sn);                        // :117
-    if (inside) sn = neg(sn);                  // :118-119
-    if (S.hw7) { F3 n = f3(T.nx, T.ny, T.nz); sn = normalize(inside ? neg(n) : n); }
-    F3 y = x + t * d;                          // distributions.h:144
-    if (S.exact_boxes) {
-        const F3 a = f3(T.ax, T.ay, T.az), pb = a + f3(q0.x, q0.y, q0.z), pc = a + f3(q0.w, q1.x, q1.y);
-        const F3 lo = f3(fminf(a.x, fminf(pb.x, pc.x)), fminf(a.y, fminf(pb.y, pc.y)), fminf(a.z, fminf(pb.z, pc.z)));
-        const F3 hi = f3(fmaxf(a.x, fmaxf(pb.x, pc.x)), fmaxf(a.y, fmaxf(pb.y, pc.y)), fmaxf(a.z, fmaxf(pb.z, pc.z)));
-        robust = pt_box_robust(lo, hi, y, d, t, S.box_c2);
-    }
-    return point_prob * len2(x - y) / fabsf(dot(d, sn)); // :68-70 (pdfOne, shading normal in hw8)
-}
-
 // ---- closest-hit walker ------------------------------------------------------------------------------------------------
 // The traversal loop of rt_wavefront.h (while-while, near-first, tie -> lowest figure index) fed from the need_trace bitmap.
 // A finished lane keeps its path index in `fin` until the next refill point, where the wave orders its record stores before
@@ -323,7 +184,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
     int sp = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayFma ray = make_ray_fma(o, d);
+    RayInv ray = make_ray_inv(o, d);
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -346,7 +207,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     const float4 *r = wf_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
-                    ray = make_ray_fma(o, d);
+                    ray = make_ray_inv(o, d);
                     cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; tie = false;
                     active = true;
                 }
@@ -368,8 +229,8 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
-                bool h0 = slab_test_fma(lo0, hi0, ray, best_t, n0);
-                bool h1 = slab_test_fma(lo1, hi1, ray, best_t, n1);
+                bool h0 = slab_test(lo0, hi0, ray, best_t, n0);
+                bool h1 = slab_test(lo1, hi1, ray, best_t, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) {
                     bool swap = n1 < n0;
@@ -421,7 +282,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE;
     int sp = 0, k = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayFma ray = make_ray_fma(o, d);
+    RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
         if (overflow) { slow = l; return; }
@@ -475,7 +336,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     const float4 *r = wf_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
-                    ray = make_ray_fma(o, d);
+                    ray = make_ray_inv(o, d);
                     cur = 0; sp = 0; k = 0; overflow = false;
                     active = true;
                 }
@@ -493,8 +354,8 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
-                bool h0 = slab_test_fma(lo0, hi0, ray, RT_T_MAX, n0);
-                bool h1 = slab_test_fma(lo1, hi1, ray, RT_T_MAX, n1);
+                bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
+                bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
                 else if (h0) cur = c0;
@@ -522,30 +383,6 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             else cur = stack[--sp][lane];
         }
     }
-}
-
-// ---- shader ------------------------------------------------------------------------------------------------------------
-// wf_shade_item behind the exactness gate: a hit that is not robust against the reference's box tests (or has a near tie)
-// and has not been through the exact walk yet goes there first (PT_SHADE_EXACT: nothing of the path's state is touched).
-RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, bool &discarded) {
-    if (S.exact_boxes) {
-        const float4 *r = wf_rec(W, slot);
-        const float4 q2 = r[2];
-        const uint32_t hit = __float_as_uint(q2.w);
-        const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
-        if (hit != WF_MISS && !(packed & WF_VERIFIED_BIT)) {
-            bool robust = !(hit & WF_NEAR_TIE_BIT);
-            if (robust) {
-                const float4 q0 = r[0], q1 = r[1];
-                const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
-                const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
-                const float4 lo = bx[0], hi = bx[1];
-                robust = pt_box_robust(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), o + q2.x * d, d, q2.x, S.box_c2);
-            }
-            if (!robust) return PT_SHADE_EXACT;
-        }
-    }
-    return wf_shade_item(S, R, W, slot, nullptr, &discarded);
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 // stack entries, contiguous (256 B per slot at depth 6), so a scattered access still moves whole cache
 // lines and the backward fold at the end of a path reads one contiguous run.
 #pragma once
-#include "rt_kernels_hw8.h"
+#include "rt_exact.h"
 
 namespace rtamd {
 namespace dev {
@@ -53,12 +53,6 @@ struct WfView {
 RT_DEV float4 *wf_rec(const WfView &W, uint32_t slot) { return W.r0 + (size_t)slot * W.stride; }
 RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0 + (size_t)slot * W.stride + 4 + 2 * level; }
 
-#define WF_MISS 0xFFFFFFFFu
-#define WF_INSIDE_BIT 0x40000000u
-#define WF_NEAR_TIE_BIT 0x80000000u   // persistent pipeline: another triangle was hit within a few ulp of the best t (never set on WF_MISS)
-#define WF_INDEX_MASK 0x3FFFFFFFu
-#define WF_SAMPLE_MASK 0x01FFFFFFu    // 25 bits of sample index in the packed word
-#define WF_VERIFIED_BIT 0x80000000u   // packed word: the hit in q2 comes from the reference-exact walk
 #define WF_CTR 8               // counter words per round
 #ifndef WF_STACK
 #define WF_STACK 30            // LDS traversal stack entries per lane: 30 KB per block, so that five blocks are resident per CU
@@ -285,6 +279,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
     int sp = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
+    bool tie = false; // another triangle hit within the slab test's tolerance of the best one: the exact walk decides (rt_exact.h)
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
     unsigned long long n_nodes = 0, n_tris = 0;
     unsigned long long w_node_iters = 0, w_leaf_phases = 0, w_leaf_lanes = 0, w_refills = 0; // wave-level (lane 0 reports)
@@ -302,7 +297,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 float4 q0 = r[0], q1 = r[1];
                 o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                 ray = make_ray_inv(o, d);
-                cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f;
+                cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; tie = false;
                 active = true;
                 if (COUNT) ray_start = w_iter;
             }
@@ -333,7 +328,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 } else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) { // traversal finished: publish the hit
-                    wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
+                    wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
                     active = false;
                     if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
                 } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
@@ -349,16 +344,20 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                     TriIsect T = load_isect(S.tri_isect + i);
                     if (COUNT) n_tris++;
                     float t, u, v; bool inside;
-                    uint32_t best_i = hit & ~WF_INSIDE_BIT;
-                    if (tri_test(T, o, d, t, u, v, inside) && (t < best_t || (t == best_t && i < best_i))) {
-                        best_t = t; best_u = u; best_v = v; hit = i | (inside ? WF_INSIDE_BIT : 0u);
+                    if (tri_test_closer(T, o, d, best_t, t, u, v, inside)) {
+                        const bool close = fabsf(t - best_t) <= 4.8e-7f * fmaxf(t, best_t);
+                        const uint32_t best_i = hit & WF_INDEX_MASK;
+                        if (t < best_t || (t == best_t && i < best_i)) {
+                            tie = close && hit != WF_MISS;
+                            best_t = t; best_u = u; best_v = v; hit = i | (inside ? WF_INSIDE_BIT : 0u);
+                        } else tie = tie || close;
                     }
                     if (T.pad) break;
                     i++;
                 }
             }
             if (sp == 0) {
-                wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit));
+                wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
                 active = false;
                 if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
             } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
@@ -555,11 +554,11 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
             if (cur != RT_EMPTY_LEAF) {
                 uint32_t i = cur & ~RT_LEAF_BIT;
                 for (;;) {
-                    bool last;
+                    bool last, robust;
                     if (COUNT) n_tris++;
-                    float term = light_pdf_one(S.lights + i, o, d, last, S.hw7 != 0);
+                    float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust);
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
-                        if (k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= WF_STACK) overflow = true;
+                        if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= WF_STACK) overflow = true; // not robust against the reference's box tests: exact walk
                         else { stack[WF_STACK - 1 - 2 * k][lane] = i; stack[WF_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
                     }
                     if (last) break;
@@ -613,7 +612,8 @@ __global__ __launch_bounds__(64) void wf_light_exact_kernel(SceneView S, WfView 
         const float4 *r = wf_rec(W, slot);
         float4 q0 = r[0], q1 = r[1];
         Counters cnt; cnt.closest = cnt.lightq = cnt.nodes = cnt.tris = 0;
-        float v = light_pdf_sum<false>(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), stack, cnt);
+        const F3 x = f3(q0.x, q0.y, q0.z), dir = f3(q0.w, q1.x, q1.y);
+        float v = S.exact_boxes ? ref_light_pdf_sum(S, x, dir, stack) : light_pdf_sum<false>(S, x, dir, stack, cnt);
         int depth = (int)(__float_as_uint(r[3].w) & 15u);
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
         *pdf = *pdf + v / (float)S.n_lights;
@@ -723,6 +723,29 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
     return wf_finish_path(S, R, W, slot, levels, tail, rng, sample);
 }
 
+// wf_shade_item behind the exactness gate: a hit that is not robust against the reference's box tests (or has a near tie)
+// and has not been through the exact walk yet goes there first (PT_SHADE_EXACT: nothing of the path's state is touched).
+RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, bool &discarded, unsigned long long *counters = nullptr) {
+    if (S.exact_boxes) {
+        const float4 *r = wf_rec(W, slot);
+        const float4 q2 = r[2];
+        const uint32_t hit = __float_as_uint(q2.w);
+        const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
+        if (hit != WF_MISS && !(packed & WF_VERIFIED_BIT)) {
+            bool robust = !(hit & WF_NEAR_TIE_BIT);
+            if (robust) {
+                const float4 q0 = r[0], q1 = r[1];
+                const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+                const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
+                const float4 lo = bx[0], hi = bx[1];
+                robust = pt_box_robust(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), o + q2.x * d, d, q2.x, S.box_c2);
+            }
+            if (!robust) return PT_SHADE_EXACT;
+        }
+    }
+    return wf_shade_item(S, R, W, slot, counters, &discarded);
+}
+
 // Throughput mode epilogue: pixel = float(1/spp) * (sum of its K stream sums, added in stream order), then the usual tonemap.
 __global__ __launch_bounds__(256) void wf_reduce_streams_kernel(RenderView R) {
     for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < R.n_pixslots; p += gridDim.x * 256u) {
@@ -757,9 +780,13 @@ __global__ __launch_bounds__(256, WF_SHADE_OCC) void wf_shade_kernel(SceneView S
         uint32_t i = base + threadIdx.x;
         if (i < count) {
             const uint32_t slot = queue[i];
-            const int todo = wf_shade_item(S, R, W, slot, counters);
-            if (todo & WF_NEXT_TRACE) wf_push(next, slot);
-            if (todo & WF_NEXT_LIGHT) wf_push(to_light, slot);
+            bool discarded = false;
+            const int todo = pt_shade_item(S, R, W, slot, discarded, counters);
+            if (todo == PT_SHADE_EXACT) W.q_slow[atomicAdd(W.ctr + WF_CTR * round + 5, 1u)] = slot; // rare (~1e-5): wf_trace_exact_kernel takes it from here
+            else {
+                if (todo & WF_NEXT_TRACE) wf_push(next, slot);
+                if (todo & WF_NEXT_LIGHT) wf_push(to_light, slot);
+            }
         }
         __syncthreads();
         if (cnt_l > WF_BUF - 256) wf_flush(to_light, W.q_light, light_count, &gbase);
@@ -768,6 +795,29 @@ __global__ __launch_bounds__(256, WF_SHADE_OCC) void wf_shade_kernel(SceneView S
     __syncthreads();
     wf_flush(to_light, W.q_light, light_count, &gbase);
     wf_flush(next, next_queue, next_count, &gbase);
+}
+
+// The few paths whose hit the shader would not take at face value (pt_shade_item): walk them again with the reference's own box
+// arithmetic (ref_closest_hit), mark the hit verified, shade them and append what they need next to the next round's queues.
+// One lane per path; a launch usually finds nothing to do (the queue holds ~1e-5 of the round's paths).
+__global__ __launch_bounds__(64) void wf_trace_exact_kernel(SceneView S, RenderView R, WfView W, uint32_t round, unsigned long long *counters) {
+    const uint32_t count = W.ctr[WF_CTR * round + 5];
+    uint32_t stack[RT_STACK_SIZE];
+    uint32_t *next_queue = W.q_trace[(round + 1) & 1], *next_count = W.ctr + WF_CTR * (round + 1) + 0, *light_count = W.ctr + WF_CTR * (round + 1) + 1;
+    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < count; i += gridDim.x * 64u) {
+        const uint32_t slot = W.q_slow[i];
+        float4 *r = wf_rec(W, slot);
+        const float4 q0 = r[0], q1 = r[1];
+        float bt, bu, bv; uint32_t hit;
+        ref_closest_hit(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), stack, bt, bu, bv, hit);
+        r[2] = make_float4(bt, bu, bv, __uint_as_float(hit));
+        float *pk = reinterpret_cast<float *>(r + 3) + 3;
+        *pk = __uint_as_float(__float_as_uint(*pk) | WF_VERIFIED_BIT);
+        if (counters) atomicAdd(&counters[12], 1ull);
+        const int todo = wf_shade_item(S, R, W, slot, counters);
+        if (todo & WF_NEXT_TRACE) next_queue[atomicAdd(next_count, 1u)] = slot;
+        if (todo & WF_NEXT_LIGHT) W.q_light[atomicAdd(light_count, 1u)] = slot;
+    }
 }
 
 } // namespace dev

@@ -531,6 +531,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * ((size_t)r * pipes + h) + 1], st));
             if (!spill && V.n_lights) hipLaunchKernelGGL(dev::wf_light_exact_kernel, dim3((unsigned)scene->n_cus), dim3(64), 0, st, V, W, r);
             hipLaunchKernelGGL(dev::wf_shade_kernel, dim3(shade_blocks[h]), dim3(256), 0, st, V, R, W, r, ctrs);
+            if (V.exact_boxes) hipLaunchKernelGGL(dev::wf_trace_exact_kernel, dim3((unsigned)scene->n_cus), dim3(64), 0, st, V, R, W, r, ctrs); // hits at a box boundary (~1e-5 of the paths)
         }
     }
     HIP_CHECK(hipGetLastError());
@@ -733,8 +734,18 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
         if (R.samples / streams >= (1 << 25)) use_wavefront = false; // the path record keeps the sample index in 25 bits
         // persistent dataflow pipeline (default) | round pipeline (RTAMD_KERNEL=wavefront, and for trees deeper than the LDS stack columns)
+        // The persistent pipeline is the default at every size: it takes reference-exact box decisions at no measurable cost (the exact
+        // walks hide behind the other waves of the workgroup) and keeps a small path population — a shard of a multi-GPU frame — near
+        // the full rate.  The round pipeline is ~5 % ahead on a full 1080p frame (20 traversal waves per CU against 16) but keeps the
+        // padded box test's answer: its exact re-walks would sit on the critical path of every round (a serial walk of the reference
+        // tree takes ~1.5 ms; RTAMD_ROUNDS_EXACT=1 switches them on for testing).  RTAMD_AUTO_GROUPS_PER_CU=n: opt into the round
+        // pipeline from n sub-tiles per CU on.
         bool use_persistent = use_wavefront && !(ksel && strcmp(ksel, "wavefront") == 0) &&
                               scene->info.bvh_depth <= WF_STACK && scene->info.light_bvh_depth <= WF_STACK && !getenv("RTAMD_WF_LDS_STACK");
+        if (use_persistent && !ksel) {
+            const uint64_t auto_groups = (uint64_t)(getenv("RTAMD_AUTO_GROUPS_PER_CU") ? atoi(getenv("RTAMD_AUTO_GROUPS_PER_CU")) : 0);
+            if (auto_groups && (uint64_t)n_work * (uint64_t)streams >= auto_groups * (uint64_t)scene->n_cus) use_persistent = false;
+        }
         if (streams > 1 && !use_wavefront) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 needs the wavefront kernels (RTAMD_KERNEL=mega or a tree beyond their limits is in effect)");
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
         if (txt_scene && scene->txt_has_triangles && p->integrator != RT_INTEGRATOR_HW5) return fail(RT_ERR_INVALID_ARG, "rt_render: a .txt scene with TRIANGLE figures renders with RT_INTEGRATOR_HW5 only");
@@ -749,6 +760,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (scene->flavor == RT_INTEGRATOR_HW6 && R.ray_depth > RT6_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw6 ray_depth above 8");
         SceneView V8 = scene->view; // per-render copy: the hw7 replay switches are render parameters, not scene state
         if (hw7) { V8.hw7 = 1; V8.last_level_emission_only = 0; V8.env_image = -1; }
+        if (!use_persistent && !getenv("RTAMD_ROUNDS_EXACT")) V8.exact_boxes = 0; // round pipeline and megakernel: the padded box test's answer stands
         uint32_t launches = 0;
         bool time_trace = false;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
@@ -860,6 +872,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                     if (scene->info.n_lights) { h_cnt[1] += c[1]; h_cnt[11] += c[4]; }
                 }
             h_cnt[0] -= h_cnt[10]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
+            h_cnt[13] = h_cnt[11];  // light sums finished by the exact kernel
         }
         if (count && use_wavefront && getenv("RTAMD_DEBUG_COUNTERS")) { // wave iterations a query stays in flight, buckets of 32
             fprintf(stderr, "[rtamd] closest-hit queries by in-flight wave iterations (x32):");
@@ -885,6 +898,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 stats->dominant_kernel_ms = time_trace ? sum : ms; stats->dominant_kernel_launches = scene->pt_launches;
                 stats->exact_closest_hits = h_cnt[12]; stats->exact_light_sums = h_cnt[13];
             } else if (use_wavefront && blocks && time_trace) {
+                stats->exact_closest_hits = h_cnt[12]; stats->exact_light_sums = h_cnt[13]; // counting renders only
                 size_t rounds = wavefront_rounds(V8, R);
                 double sum = 0;
                 const size_t n_launch = rounds * (size_t)scene->wf_pipes; // with more than one pipeline a launch shares the GPU with the other pipelines' kernels

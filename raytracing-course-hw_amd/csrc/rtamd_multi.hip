@@ -58,6 +58,7 @@ struct rt_multi {
     size_t frame_cap_rgb = 0, frame_cap_rgb8 = 0;
     ~rt_multi() {
         for (size_t i = 0; i < dev.size(); i++) {
+            if (!dev[i].scene && !dev[i].stream && !dev[i].d_rgb && !dev[i].d_rgb8) continue; // nothing was created on it (it may not even exist)
             (void)hipSetDevice(dev[i].device);
             if (dev[i].scene) rt_scene_destroy(dev[i].scene);
             if (dev[i].d_rgb) (void)hipFree(dev[i].d_rgb);
@@ -65,11 +66,12 @@ struct rt_multi {
             if (dev[i].stream) (void)hipStreamDestroy(dev[i].stream);
             if (dev[i].done) (void)hipEventDestroy(dev[i].done);
         }
-        if (!dev.empty()) (void)hipSetDevice(dev[0].device);
+        if (!dev.empty() && dev[0].scene) (void)hipSetDevice(dev[0].device);
         for (float *p : land_rgb) if (p) (void)hipFree(p);
         for (uint8_t *p : land_rgb8) if (p) (void)hipFree(p);
         if (frame_rgb) (void)hipFree(frame_rgb);
         if (frame_rgb8) (void)hipFree(frame_rgb8);
+        (void)hipGetLastError(); // a failed teardown call must not surface in somebody else's next launch check
     }
 };
 

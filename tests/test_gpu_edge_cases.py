@@ -74,9 +74,10 @@ def test_emissive_point_light_box_rounding(rt):
     """An emissive zero-area triangle makes light sampling aim rays EXACTLY at a vertex, i.e. through the corner of
     light-BVH boxes.  There the reference's own slab test (6 divisions on a re-centred box, hw8/src/primitives.cpp:29-53)
     rejects a box by one ulp although the ray hits a triangle inside it, while a conservative padded test keeps it.
-    The persistent pipeline (default) sends such hits — and only those — through walks with the reference's own box
-    arithmetic and must reproduce the oracle bit for bit; the round pipeline and the megakernel keep the padded test's
-    answer (a handful of samples differ, the random stream stays in sync)."""
+    The persistent pipeline (the default) sends such hits — and only those — through walks with the reference's own box
+    arithmetic and must reproduce the oracle bit for bit; so does the round pipeline under RTAMD_ROUNDS_EXACT=1 (off by default
+    there: its exact re-walks sit on every round's critical path).  The megakernel and the plain round pipeline keep the padded
+    test's answer (a handful of samples differ, the random stream stays in sync)."""
     import os
     sd0 = pin_cases.random_triangle_scene(n=120, seed=8)
     pos = sd0.positions.copy().reshape(-1, 3, 3)
@@ -91,19 +92,21 @@ def test_emissive_point_light_box_rounding(rt):
         scene = rt.Scene(sd)
         imgs[kernel], _, _ = scene.render(48, 36, 6)
         scene.close()
-    os.environ.pop("RTAMD_KERNEL", None)
     assert np.array_equal(imgs["wavefront"], imgs["mega"], equal_nan=True)
     bad = int((np.abs(imgs["mega"].astype(np.float64) - ref).max(axis=2) > 1e-3).sum())
     print(f"emissive point light: {bad} of {48 * 36} pixels differ from the oracle with the padded box test")
-    assert bad <= 10
-    os.environ["RTAMD_KERNEL"] = "persistent"
-    scene = rt.Scene(sd)
-    rgb, _, st = scene.render(48, 36, 6)
-    scene.close()
+    assert 0 < bad <= 10
+    os.environ["RTAMD_ROUNDS_EXACT"] = "1"
+    for kernel, pipeline in (("persistent", rt.RT_PIPELINE_PERSISTENT), ("wavefront", rt.RT_PIPELINE_ROUNDS)):
+        os.environ["RTAMD_KERNEL"] = kernel
+        scene = rt.Scene(sd)
+        rgb, _, st = scene.render(48, 36, 6, counters=True)
+        scene.close()
+        print(f"{kernel}: exact closest hits {st.exact_closest_hits}, exact light sums {st.exact_light_sums} of {st.closest_hit_queries} + {st.light_pdf_queries} queries")
+        assert st.pipeline == pipeline and st.exact_light_sums > 0
+        assert np.array_equal(rgb, ref, equal_nan=True)
     os.environ.pop("RTAMD_KERNEL", None)
-    print(f"persistent pipeline: exact closest hits {st.exact_closest_hits}, exact light sums {st.exact_light_sums} of {st.closest_hit_queries} + {st.light_pdf_queries} queries")
-    assert st.pipeline == rt.RT_PIPELINE_PERSISTENT and st.exact_light_sums > 0
-    assert np.array_equal(rgb, ref, equal_nan=True)
+    os.environ.pop("RTAMD_ROUNDS_EXACT", None)
 
 
 @pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 5, 0), (9, 7, 2, 1), (8, 8, 3, 2), (33, 5, 2, 16), (24, 16, 1, 6)])

@@ -159,8 +159,19 @@ def test_full_config_1920x1080x256_crops_match_oracle(rt, tmp_path):
     assert ntris == 268816 and sd.positions.shape[0] == ntris
     scene = rt.Scene(sd)
     rgb, rgb8, st = scene.render(1920, 1080, 256)
-    print(f"full frame: {st.kernel_ms:.1f} ms kernel = {1920 * 1080 * 256 / st.kernel_ms / 1e3:.1f} Msamples/s")
+    print(f"full frame: pipeline {st.pipeline}, {st.kernel_ms:.1f} ms kernel = {1920 * 1080 * 256 / st.kernel_ms / 1e3:.1f} Msamples/s")
     assert np.isfinite(rgb).all() and rgb.mean() > 0.05
+    # the other organisation of the two that take reference-exact box decisions must give the very same frame
+    os.environ["RTAMD_KERNEL"] = "wavefront" if st.pipeline == rt.RT_PIPELINE_PERSISTENT else "persistent"
+    os.environ["RTAMD_ROUNDS_EXACT"] = "1"   # the round pipeline's exact re-walks are off by default (they serialise every round)
+    try:
+        rgb_b, rgb8_b, st_b = scene.render(1920, 1080, 256)
+    finally:
+        os.environ.pop("RTAMD_KERNEL", None)
+        os.environ.pop("RTAMD_ROUNDS_EXACT", None)
+    print(f"full frame: pipeline {st_b.pipeline}, {st_b.kernel_ms:.1f} ms kernel = {1920 * 1080 * 256 / st_b.kernel_ms / 1e3:.1f} Msamples/s")
+    assert {st.pipeline, st_b.pipeline} == {rt.RT_PIPELINE_PERSISTENT, rt.RT_PIPELINE_ROUNDS}
+    assert np.array_equal(rgb, rgb_b) and np.array_equal(rgb8, rgb8_b)
     orc = oracle_lib.Hw8Oracle(sd)
     worst = 0.0
     # 36 crops: the eight of round 1, tile (192,192) — the worst tile of round 1's 300-tile sweep, where the padded box test of the

@@ -424,6 +424,26 @@ RT_DEV F3 material_brdf(F3 base_color, float base_metallic, F3 l, F3 v, F3 n, F3
     return (1.0f - metallic) * dielectric + metallic * metal;
 }
 
+// material_brdf with its two products formed by the caller (bc = base_color * color, metallic = texture metallic * baseMetallic —
+// the same single multiplications, so the same values): the shader computes them before it samples a direction and so carries
+// four values instead of eight through the sampling code.
+RT_DEV F3 material_brdf_pre(F3 bc, float metallic, F3 l, F3 v, F3 n, float alpha) {
+    F3 h = normalize(l + v);
+    float specular = specular_brdf(l, v, n, alpha * alpha);
+    F3 metal = f3(0.f, 0.f, 0.f), dielectric = f3(0.f, 0.f, 0.f);
+    if (metallic > 0 && dot(v, n) >= 0 && dot(l, n) >= 0) {
+        F3 ft = fresnel_term(bc, f3(1.f, 1.f, 1.f), v, h);
+        metal = specular * ft;
+    }
+    if (metallic < 1) {
+        F3 diffuse = f3(0.f, 0.f, 0.f);
+        if (dot(l, n) >= 0) diffuse = (float)(1. / RT_PI) * bc;
+        F3 ft = fresnel_term(f3(0.04f, 0.04f, 0.04f), f3(1.f, 1.f, 1.f), v, h);
+        dielectric = diffuse * (f3(1.f, 1.f, 1.f) - ft) + specular * ft;
+    }
+    return (1.0f - metallic) * dielectric + metallic * metal;
+}
+
 // hw7/src/include/material.h:44-61: per-material colour and metallic only, and none of hw8's v.n / l.n gates
 RT_DEV F3 material_brdf_hw7(F3 base_color, float base_metallic, F3 l, F3 v, F3 n, float alpha2) {
     F3 h = normalize(l + v);

@@ -18,7 +18,7 @@ struct Shaded {
 
 // Everything Scene::getColor does between the intersection and the direction sampling
 // (scene.cpp:99-149): interpolate attributes, fetch the material, sample the textures, normal map.
-RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh, F3 &base_color, float &base_metallic) {
+RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
     const float4 *qi = reinterpret_cast<const float4 *>(S.tri_isect + h.idx);
     float4 i0 = qi[0], i1 = qi[1];
     F3 n = f3(i0.w, i1.x, i1.y);
@@ -44,7 +44,7 @@ RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh,
     base_color = f3(m0.x, m0.y, m0.z); base_metallic = m0.w;
     int tex_color = (int)__float_as_uint(m2.x), tex_emis = (int)__float_as_uint(m2.y);
     int tex_mr = (int)__float_as_uint(m2.z), tex_nrm = (int)__float_as_uint(m2.w);
-    if (S.hw7) { // hw7/src/scene.cpp:29-61: factors only
+    if (hw7) { // hw7/src/scene.cpp:29-61: factors only
         sh.color = f3(1.f, 1.f, 1.f); sh.emission = f3(m1.x, m1.y, m1.z); sh.sn = sn;
         sh.alpha = m1.w * m1.w;                                                      // pow(roughnessFactor, 2.0), :44
         sh.metallic = 1.f;
@@ -83,8 +83,11 @@ RT_DEV F3 emission_fetch(const SceneView &S, const HitRec &h) {
     return emission;
 }
 
+// ENV = false compiles the environment-map lookup out: its inlined double-precision atan2 / asin are the largest register users of
+// the shading code, and a kernel that can never reach them (scene without an environment map) spills half as many registers.
+template <bool ENV = true>
 RT_DEV F3 miss_color(const SceneView &S, F3 d) { // scene.cpp:90-97
-    if (S.env_image < 0) return f3(S.bg);
+    if (!ENV || S.env_image < 0) return f3(S.bg);
     float tx = (float)(0.5 + 0.5 * atan2((double)d.z, (double)d.x) / RT_PI);
     float ty = (float)(0.5 - asin((double)d.y) / RT_PI);
     return sample_texture(S, S.env_image, tx, ty, true);
@@ -101,7 +104,7 @@ RT_DEV F3 trace_path(const SceneView &S, int ray_depth, Rng &rng, F3 o, F3 d, ui
         HitRec h = closest_hit<COUNT>(S, o, d, stack, cnt);
         if (h.idx < 0) { tail = miss_color(S, d); break; }
         F3 ng, base_color; float base_metallic; Shaded sh;
-        shade_fetch(S, h, ng, sh, base_color, base_metallic);
+        shade_fetch(S, h, ng, sh, base_color, base_metallic, S.hw7 != 0);
         F3 x = o + h.t * d;                                                    // scene.cpp:104
         F3 xo = x + 9.99999974737875163555e-05f * ng;                          // x + eps * geomNorma, eps = (float)1e-4L
         // Mix::sample (distributions.h:256-265)

@@ -178,7 +178,7 @@ RT_DEV void pt_complete(PtShared &sh, uint32_t l, uint32_t bit, bool doit) {
 // the LDS hand-off with one workgroup-scope release.
 template <bool COUNT>
 RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
-                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
+                           const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
     bool active = false, tie = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
@@ -276,7 +276,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 // ---- light-sum walker (wf_light_loop_lean of rt_wavefront.h fed from the need_light bitmap) ----------------------------------
 template <bool COUNT>
 RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
-                           const int shade_thr, unsigned long long &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
+                           const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
     bool active = false, overflow = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE;
@@ -386,7 +386,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, int FEAT>
 __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, RenderView R, WfView W, PtParams P) {
     __shared__ PtShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -454,7 +454,8 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
     // ---- scheduler: every wave picks a role whenever it is idle ----------------------------------------------------------------
     uint32_t(*stack)[64] = sh.stack[wave];
     const int shade_thr = P.shade_thr0 + (int)wave * P.shade_thr_step;
-    unsigned long long n_closest = 0, n_light = 0, n_nodes = 0, n_tris = 0, n_xtrace = 0, n_xlight = 0, n_discarded = 0;
+    uint32_t n_closest = 0, n_light = 0, n_xtrace = 0, n_xlight = 0, n_discarded = 0; // per wave and launch: well below 2^32
+    unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t idle_spins = 0;
     PtProf prof;
     unsigned long long t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
             int todo = 0;
             bool discarded = false;
-            if (got != PT_NONE) todo = pt_shade_item(S, R, W, pt_slot(sh, got), discarded);
+            if (got != PT_NONE) todo = pt_shade_item<FEAT>(S, R, W, pt_slot(sh, got), discarded);
             n_discarded += __popcll(__ballot(discarded));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const bool next = got != PT_NONE && (todo & WF_NEXT_TRACE), with_light = next && (todo & WF_NEXT_LIGHT);
@@ -564,11 +565,11 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
         for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
     }
     if (lane == 0 && P.counters) {
-        if (n_closest) atomicAdd(&P.counters[0], n_closest);
-        if (n_light) atomicAdd(&P.counters[1], n_light);
-        if (n_discarded) atomicAdd(&P.counters[10], n_discarded);
-        if (n_xtrace) atomicAdd(&P.counters[12], n_xtrace);
-        if (n_xlight) atomicAdd(&P.counters[13], n_xlight);
+        if (n_closest) atomicAdd(&P.counters[0], (unsigned long long)n_closest);
+        if (n_light) atomicAdd(&P.counters[1], (unsigned long long)n_light);
+        if (n_discarded) atomicAdd(&P.counters[10], (unsigned long long)n_discarded);
+        if (n_xtrace) atomicAdd(&P.counters[12], (unsigned long long)n_xtrace);
+        if (n_xlight) atomicAdd(&P.counters[13], (unsigned long long)n_xlight);
     }
     if (COUNT && P.counters) {
         atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris);

@@ -624,6 +624,12 @@ __global__ __launch_bounds__(64) void wf_light_exact_kernel(SceneView S, WfView 
 // Returns what the slot needs next: WF_NEXT_TRACE (its record holds a ray to trace: a new bounce or the next sample's camera
 // ray), | WF_NEXT_LIGHT (that ray is also a bounce's light-pdf query), WF_PARKED (the next sample's camera ray is in the
 // record but belongs to the frame's next phase), or 0 (the pixel is finished and written).
+// FEAT: which optional features the shading code is compiled with (WF_FEAT_ENV: environment-map lookup on a miss; WF_FEAT_HW7: the
+// hw7 material model).  A kernel variant without a feature the render cannot use carries less register pressure: the inlined
+// double-precision atan2 / asin of the environment lookup alone double the spills of the persistent kernel.
+#define WF_FEAT_ENV 1
+#define WF_FEAT_HW7 2
+template <int FEAT = WF_FEAT_ENV | WF_FEAT_HW7>
 RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, unsigned long long *counters, bool *discarded = nullptr) {
     float4 *r = wf_rec(W, slot);
     float4 q0 = r[0], q1 = r[1], q2 = r[2];
@@ -676,7 +682,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
     if (!ended) {
         const uint32_t hit = __float_as_uint(q2.w);
         levels = depth;
-        if (hit == WF_MISS) { ended = true; tail = miss_color(S, d); }
+        if (hit == WF_MISS) { ended = true; tail = miss_color<(FEAT & WF_FEAT_ENV) != 0>(S, d); }
         else {
             HitRec h;
             h.idx = (int)(hit & WF_INDEX_MASK); h.inside = (hit & WF_INSIDE_BIT) != 0; h.t = q2.x; h.u = q2.y; h.v = q2.z;
@@ -691,28 +697,41 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
                 else { rng_u01(rng); rng_u01(rng); }
                 ended = true;
             } else {
-                F3 ng, base_color; float base_metallic; Shaded sh;
-                shade_fetch(S, h, ng, sh, base_color, base_metallic);
-                F3 x = f3(q0.x, q0.y, q0.z) + h.t * d;                                 // scene.cpp:104
-                F3 xo = x + 9.99999974737875163555e-05f * ng;                          // x + eps * geomNorma
+                const bool hw7 = (FEAT & WF_FEAT_HW7) && S.hw7;
+                float4 *e = wf_entry(W, slot, depth);
+                F3 bc; float metallic_eff, alpha; F3 sn;
+                {
+                    // Everything the sampling code below does not need leaves the registers here: the emission and the next ray's
+                    // origin go to the path's record at once (their final places), colour and metallic shrink to the products
+                    // the BRDF uses.  (hw7: colour texture = 1 and texture metallic = 1, so the products are the plain factors.)
+                    F3 ng, base_color; float base_metallic; Shaded sh;
+                    shade_fetch(S, h, ng, sh, base_color, base_metallic, hw7);
+                    F3 x = f3(q0.x, q0.y, q0.z) + h.t * d;                             // scene.cpp:104
+                    F3 xo = x + 9.99999974737875163555e-05f * ng;                      // x + eps * geomNorma
+                    e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, 0.f);
+                    r[0] = make_float4(xo.x, xo.y, xo.z, 0.f);                        // the next ray doubles as the light query
+                    bc = base_color * sh.color;
+                    metallic_eff = sh.metallic * base_metallic;
+                    alpha = sh.alpha; sn = sh.sn;
+                }
                 int comp = (int)(rng_u01(rng) * (float)S.n_components);               // distributions.h:257
                 F3 nd;
-                if (comp == 0) nd = cosine_sample(rng, sh.sn);
-                else if (comp == 2) nd = light_sample(S, rng, xo);
-                else nd = vndf_sample(rng, sh.sn, d, sh.alpha);
-                F3 brdf = S.hw7 ? material_brdf_hw7(base_color, base_metallic, nd, neg(d), sh.sn, sh.alpha * sh.alpha)
-                                : material_brdf(base_color, base_metallic, nd, neg(d), sh.sn, sh.color, sh.metallic, sh.alpha);
+                if (comp == 0) nd = cosine_sample(rng, sn);
+                else if (comp == 2) { const float4 xq = r[0]; nd = light_sample(S, rng, f3(xq.x, xq.y, xq.z)); }
+                else nd = vndf_sample(rng, sn, d, alpha);
+                F3 brdf = hw7 ? material_brdf_hw7(bc, metallic_eff, nd, neg(d), sn, alpha * alpha)
+                              : material_brdf_pre(bc, metallic_eff, nd, neg(d), sn, alpha);
                 const float epsf = 9.99999974737875163555e-05f;
                 if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) {             // scene.cpp:154-156
-                    ended = true; tail = sh.emission;
+                    const float4 e0 = e[0];
+                    ended = true; tail = f3(e0.x, e0.y, e0.z);
                 } else {
                     float pdf = 0.f;                                                   // distributions.h:268-276, first two terms
-                    pdf += cosine_pdf(sh.sn, nd);
-                    pdf += vndf_pdf(sh.sn, nd, d, sh.alpha);
-                    float4 *e = wf_entry(W, slot, depth);
-                    e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, pdf);
-                    e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sh.sn));
-                    r[0] = make_float4(xo.x, xo.y, xo.z, nd.x);                       // the next ray doubles as the light query
+                    pdf += cosine_pdf(sn, nd);
+                    pdf += vndf_pdf(sn, nd, d, alpha);
+                    reinterpret_cast<float *>(e)[3] = pdf;
+                    e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sn));
+                    reinterpret_cast<float *>(r)[3] = nd.x;
                     r[1] = make_float4(nd.y, nd.z, __uint_as_float(rng.x), rng.saved);
                     reinterpret_cast<float *>(r + 3)[3] = __uint_as_float(wf_pack(depth, rng.has_saved, sample, true));
                     return WF_NEXT_TRACE | (S.n_lights ? WF_NEXT_LIGHT : 0);           // traced speculatively beside its own light-pdf sum
@@ -725,6 +744,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
 
 // wf_shade_item behind the exactness gate: a hit that is not robust against the reference's box tests (or has a near tie)
 // and has not been through the exact walk yet goes there first (PT_SHADE_EXACT: nothing of the path's state is touched).
+template <int FEAT = WF_FEAT_ENV | WF_FEAT_HW7>
 RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, bool &discarded, unsigned long long *counters = nullptr) {
     if (S.exact_boxes) {
         const float4 *r = wf_rec(W, slot);
@@ -743,7 +763,7 @@ RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &
             if (!robust) return PT_SHADE_EXACT;
         }
     }
-    return wf_shade_item(S, R, W, slot, counters, &discarded);
+    return wf_shade_item<FEAT>(S, R, W, slot, counters, &discarded);
 }
 
 // Throughput mode epilogue: pixel = float(1/spp) * (sum of its K stream sums, added in stream order), then the usual tonemap.

@@ -655,8 +655,19 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
             }
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
-            if (count) hipLaunchKernelGGL(dev::pt_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
-            else hipLaunchKernelGGL(dev::pt_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
+            // kernel variant by the features this render can reach (fewer features, fewer spilled registers): the hw7 integrator has no
+            // environment map; an hw8 render needs the environment lookup only when the scene has a map
+            const int feat = V.hw7 ? WF_FEAT_HW7 : (V.env_image >= 0 ? WF_FEAT_ENV : 0);
+            const dim3 grid(blocks), block(PT_THREADS);
+            if (count) {
+                if (feat == WF_FEAT_HW7) hipLaunchKernelGGL((dev::pt_persistent_kernel<true, WF_FEAT_HW7>), grid, block, 0, stream, V, Rp, W, P);
+                else if (feat == WF_FEAT_ENV) hipLaunchKernelGGL((dev::pt_persistent_kernel<true, WF_FEAT_ENV>), grid, block, 0, stream, V, Rp, W, P);
+                else hipLaunchKernelGGL((dev::pt_persistent_kernel<true, 0>), grid, block, 0, stream, V, Rp, W, P);
+            } else {
+                if (feat == WF_FEAT_HW7) hipLaunchKernelGGL((dev::pt_persistent_kernel<false, WF_FEAT_HW7>), grid, block, 0, stream, V, Rp, W, P);
+                else if (feat == WF_FEAT_ENV) hipLaunchKernelGGL((dev::pt_persistent_kernel<false, WF_FEAT_ENV>), grid, block, 0, stream, V, Rp, W, P);
+                else hipLaunchKernelGGL((dev::pt_persistent_kernel<false, 0>), grid, block, 0, stream, V, Rp, W, P);
+            }
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch + 1], stream));
             launch++;
         }

@@ -355,7 +355,7 @@ def main():
         base["config"] = {"workload": args.workload if (W, H) == (base_w, base_h) else f"{args.workload} grown to {W}x{H} ({world} x {base_w}x{base_h} pixels)",
                           "scene": "synth_room_v1 (seed 20241223)", "triangles": int(info.n_triangles),
                           "emissive_triangles": int(info.n_lights), "width": W, "height": H, "spp": SPP, "ray_depth": 6,
-                          "parallelism": f"pixel tiles {TILE}x{TILE} round-robin over {world} GPU(s)" + (", RCCL gather of u8 tiles" if world > 1 else ""),
+                          "parallelism": f"pixel tiles {TILE}x{TILE} round-robin over {world} GPU(s)" + ((", gloo gather of u8 tiles (one-GPU rehearsal)" if rehearsal else ", RCCL gather of u8 tiles") if world > 1 else ""),
                           "bvh_nodes": int(info.n_bvh_nodes), "bvh_depth": int(info.bvh_depth), "light_bvh_depth": int(info.light_bvh_depth), "scene_prep_ms": round(info.prep_ms, 1), "scene_upload_ms": round(info.upload_ms, 1),
                           "scene_load_ms": round(t_load * 1e3, 1), "device_bytes": int(info.device_bytes)}
         base["roofline"] = roofline

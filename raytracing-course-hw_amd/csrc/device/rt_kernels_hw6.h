@@ -264,6 +264,7 @@ struct Frame6 {
 // camera sample at once instead of idling until the longest path of the wave has finished.
 struct Machine6 {
     Frame6 frames[RT6_MAX_DEPTH];
+    uint32_t n_closest, n_light; // queries answered for this lane (RT_FLAG_COUNTERS)
     int fp;
     bool evaluating; // true: evaluate getColor(o, d, ray_depth - fp) ; false: `ret` is a finished child value
     F3 o, d, ret;
@@ -280,6 +281,7 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
         if (evaluating) {
             if (fp >= ray_depth) { ret = f3(0.f, 0.f, 0.f); evaluating = false; continue; }   // recLimit == 0
             Hit6 h = closest_hit6(S, o, d, stack);
+            M.n_closest++;
             if (h.slot < 0) { ret = f3(S.bg); evaluating = false; continue; }
             Tri6Regs T = load_tri6(S.tris + h.slot);
             const float4 *qm = reinterpret_cast<const float4 *>(S.materials + T.material);
@@ -306,7 +308,7 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
                 if (dot(nd, norma) < 0) { ret = emission; evaluating = false; continue; }       // scene.cpp:64-66
                 float pdf = 0.f;
                 pdf += smax(0.f, dot(nd, norma) / RT_PI_F);                                     // distributions.h:55-58
-                if (S.n_components == 2) pdf += light_pdf_sum6_fast(S, xo, nd, stack, deep_stack) / (float)S.n_lights;
+                if (S.n_components == 2) { pdf += light_pdf_sum6_fast(S, xo, nd, stack, deep_stack) / (float)S.n_lights; M.n_light++; }
                 pdf = pdf / (float)S.n_components;
                 float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)dot(nd, norma));       // scene.cpp:69
                 f.kind = F6_MUL; f.emission = emission; f.mult = k * color;
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(64, RT6_MIN_WAVES) void render_hw6_kernel(SceneView
     uint32_t *stack = LDS_STACK ? lds_stack + lane * RT6_LDS_STRIDE : deep_stack;
     const uint32_t n_slots = n_work * 64u;   // pixel slots in the tile order of slot_to_pixel()
     Machine6 M;
+    M.n_closest = 0; M.n_light = 0;
     machine6_start(M, f3(0.f, 0.f, 0.f), f3(0.f, 0.f, 1.f));
     Rng rng; rng_seed(rng, 0u);
     F3 color = f3(0.f, 0.f, 0.f);
@@ -422,6 +425,7 @@ __global__ __launch_bounds__(64, RT6_MIN_WAVES) void render_hw6_kernel(SceneView
             }
         }
     }
+    if (R.counters) { atomicAdd(&R.counters[0], (unsigned long long)M.n_closest); atomicAdd(&R.counters[1], (unsigned long long)M.n_light); }
 }
 
 } // namespace dev

@@ -256,3 +256,28 @@ def test_persistent_pipeline_phases_and_deals_do_not_change_pixels(rt, monkeypat
         thr2, _, stt = scene.render(w, h, 12, sample_streams=3)
         assert np.array_equal(thr2, thr1, equal_nan=True)
     scene.close()
+
+
+def test_persistent_pipeline_in_several_passes(rt, monkeypatch):
+    """A frame with more path slots than the workgroups' LDS bitmaps hold (256 workgroups x 32,768 paths) is rendered in several
+    passes over disjoint slot ranges; with RTAMD_PT_BLOCKS=2 a 400x300 frame already needs two (and each pass its own two
+    phases).  Replay mode, shards and throughput mode (whose stream index comes from the global slot) must not change."""
+    import pin_cases
+    sd = pin_cases.random_triangle_scene(n=300, seed=12)
+    w, h, spp = 400, 300, 4
+    scene = rt.Scene(sd)
+    one, one8, st1 = scene.render(w, h, spp)
+    thr1, _, _ = scene.render(w, h, 8, sample_streams=2)
+    shard1, _, _ = scene.render(w, h, spp, shard_index=2, shard_count=3, tile=32)
+    monkeypatch.setenv("RTAMD_PT_BLOCKS", "2")
+    monkeypatch.setenv("RTAMD_PT_PHASE0", "1")
+    two, two8, st2 = scene.render(w, h, spp)
+    thr2, _, stt = scene.render(w, h, 8, sample_streams=2)
+    shard2, _, _ = scene.render(w, h, spp, shard_index=2, shard_count=3, tile=32)
+    scene.close()
+    assert st1.launches == 1 and st2.launches == 4 and stt.launches >= 4 + 1   # 2 passes x 2 phases (+ the stream reduction)
+    assert np.array_equal(two, one, equal_nan=True) and np.array_equal(two8, one8)
+    assert np.array_equal(thr2, thr1, equal_nan=True) and np.array_equal(shard2, shard1, equal_nan=True)
+    assert (st2.closest_hit_queries, st2.light_pdf_queries) == (st1.closest_hit_queries, st1.light_pdf_queries)
+    crop_ref, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp, rect=(180, 130, 40, 40))
+    assert np.array_equal(two[130:170, 180:220], crop_ref, equal_nan=True)

@@ -103,7 +103,7 @@ struct PtWave {
     uint32_t cur[5];
 };
 
-RT_DEV uint32_t pt_slot(const PtShared &sh, uint32_t l) { return (sh.groups[l >> 6] << 6) | (l & 63u); }
+template <class SH> RT_DEV uint32_t pt_slot(const SH &sh, uint32_t l) { return (sh.groups[l >> 6] << 6) | (l & 63u); }
 RT_DEV int pt_count(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // a fresh LDS read each time
 
 // Hands paths to the lanes that want one.  The wave reads 64 bitmap words at once (lane i: word cursor + i), then takes whole
@@ -154,7 +154,7 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
 }
 
 // Sets the bit of path l in queue q for the lanes with `doit` (wave-uniform call).
-RT_DEV void pt_push(PtShared &sh, int q, uint32_t l, bool doit) {
+template <class SH> RT_DEV void pt_push(SH &sh, int q, uint32_t l, bool doit) {
     if (doit) atomicOr(&sh.need[q][l >> 5], 1u << (l & 31u));
     const unsigned long long m = __ballot(doit);
     if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sh.cnt[q], (int)__popcll(m));
@@ -162,7 +162,7 @@ RT_DEV void pt_push(PtShared &sh, int q, uint32_t l, bool doit) {
 
 // One of the two walks of path l is done (its results are in HBM, ordered before this call by the caller's release fence):
 // clear its pending bit; whoever clears the last one hands the path to the shaders.  Wave-uniform call.
-RT_DEV void pt_complete(PtShared &sh, uint32_t l, uint32_t bit, bool doit) {
+template <class SH> RT_DEV void pt_complete(SH &sh, uint32_t l, uint32_t bit, bool doit) {
     bool ready = false;
     if (doit) {
         const uint32_t shift = (l & 15u) * 2u;

@@ -1,0 +1,548 @@
+// Persistent dataflow form of the hw6 replay path tracer (BASELINE.json configs[2]): the organisation of rt_persistent.h applied to
+// hw6's integrator (hw6/src/scene.cpp:47-105) with its binary recursion tree.
+//
+// render_hw6_kernel (rt_kernels_hw6.h) keeps a whole path machine per lane — an 8-frame recursion stack in scratch, walks that are
+// wave-synchronous but never refill, so every step of a wave lasts as long as its longest walk through the scene (a glass bunny in
+// practice6_2).  Here the frames of a path live in its HBM record and the work is cut at the walks:
+//
+//   closest-hit walkers / light-sum walkers   the while-while loops over hw6's own trees, lanes refilled from LDS bitmaps;
+//   shaders                                   run the frame machine of a path between two walks: finish the pending DIFFUSE bounce
+//                                             (its light-pdf sum has arrived), shade the new hit, push a frame, or unwind frames
+//                                             (MUL / dielectric reflect -> Fresnel -> one uniform -> maybe the refracted child)
+//                                             until the path needs its next walk, its next camera sample, or is finished.
+//
+// The random stream of a pixel is consumed only by the shader steps, in the reference's order (the reflected subtree completes before
+// the dielectric's uniform is drawn, scene.cpp:77,92), so the replay is the one of rt_kernels_hw6.h; the arithmetic is the same code.
+// As in rt_persistent.h a DIFFUSE bounce's sampled direction is traced for the next hit while its light-pdf sum is walked (the two
+// rays share the direction but not the origin here: x + eps*d for the child, x + eps*n for the pdf, scene.cpp:63,68).
+#pragma once
+#include "rt_persistent.h"
+#include "rt_kernels_hw6.h"
+
+namespace rtamd {
+namespace dev {
+
+#define P6_STACK 36                  // LDS stack entries per lane (RT6_LDS_STACK: practice6_2's own trees are up to 36 deep)
+#define P6_MAX_PATHS 8192            // paths per workgroup: with 36-entry stacks the bitmaps get 8 KB
+#define P6_NW (P6_MAX_PATHS / 32)
+#define P6_Q_SLOW 3                  // light sums with more than two hits: the complete per-lane light_pdf_sum6_fast
+#define P6_REC 48u                   // float4 per path record: 8 + 5 per frame x RT6_MAX_DEPTH
+// record: r0 = o.xyz d.x | r1 = d.yz rng.x rng.saved | r2 = hit t, figure slot, inside, - | r3 = accum.xyz packed
+//         r4 = light-query origin xo.xyz, light sum (raw)  | r5 = pending emission.xyz, cosine pdf | r6 = pending colour.xyz, d.n
+//         frame f at r[8 + 5 f]: emission.xyz kind | mult.xyz inside | x.xyz ior | dn.xyz - | norma.xyz -
+// packed: fp:4 | has_saved:16 | pending:32 | light_only:64 (the pending bounce's child is beyond the depth limit: no trace) | sample << 8
+#define P6_PENDING 32u
+#define P6_LIGHT_ONLY 64u
+// actions of p6_advance
+#define P6_TRACE 1
+#define P6_LIGHT 2
+#define P6_PARKED 8
+
+struct P6Shared {
+    uint32_t stack[PT_WAVES][P6_STACK][64];
+    uint32_t need[4][P6_NW];
+    uint32_t pending[P6_NW * 2];
+    uint32_t groups[P6_MAX_PATHS / 64];
+    uint32_t cost[P6_MAX_PATHS / 64];     // shader steps per local sub-tile in this launch: the load measure of the re-deal
+    int cnt[16];
+};
+
+struct W6View { float4 *r0; uint32_t slot_base; };
+RT_DEV float4 *p6_rec(const W6View &W, uint32_t slot) { return W.r0 + (size_t)slot * P6_REC; }
+RT_DEV uint32_t p6_pack(int fp, bool has_saved, uint32_t sample, uint32_t flags) { return (uint32_t)fp | (has_saved ? 16u : 0u) | flags | (sample << 8); }
+
+RT_DEV void p6_camera_ray(const SceneView6 &S, const RenderView &R, Rng &rng, int x, int y, F3 &o, F3 &d) { // hw6/src/scene.cpp:111-126 (direction not normalised)
+    float nx = (float)x + rng_u01(rng);
+    float ny = (float)y + rng_u01(rng);
+    float cx = R.tan_fov_x * (2 * nx / (float)R.width - 1);
+    float cy = S.tan_fov_y * (2 * ny / (float)R.height - 1);
+    o = f3(S.cam_pos);
+    d = cx * f3(S.cam_right) - cy * f3(S.cam_up) + f3(S.cam_fwd);
+}
+
+// ---- shader: the frame machine of one path between two walks (machine6_step of rt_kernels_hw6.h, cut at the walks) --------------
+RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W, uint32_t slot) {
+    const float epsf = 9.99999974737875163555e-05f; // (float)1e-4L
+    float4 *r = p6_rec(W, slot);
+    const float4 q1 = r[1];
+    Rng rng; rng.x = __float_as_uint(q1.z); rng.saved = q1.w;
+    const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
+    int fp = (int)(packed & 15u);
+    rng.has_saved = (packed & 16u) != 0;
+    uint32_t sample = packed >> 8;
+    F3 ret = f3(0.f, 0.f, 0.f);
+    bool returning = false;
+    if (packed & P6_PENDING) {
+        // the DIFFUSE bounce at level fp: its light-pdf sum is in r4.w now (scene.cpp:67-69, distributions.h:288-300)
+        const float4 q4 = r[4], q5 = r[5], q6 = r[6];
+        float pdf = 0.f;
+        pdf += q5.w;
+        if (S.n_components == 2) pdf += q4.w / (float)S.n_lights;
+        pdf = pdf / (float)S.n_components;
+        const float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)q6.w);                   // scene.cpp:69
+        float4 *f = r + 8 + 5 * fp;
+        f[0] = make_float4(q5.x, q5.y, q5.z, __uint_as_float((uint32_t)F6_MUL));
+        const F3 mult = k * f3(q6.x, q6.y, q6.z);
+        f[1] = make_float4(mult.x, mult.y, mult.z, 0.f);
+        fp++;
+        if (packed & P6_LIGHT_ONLY) returning = true;                                          // the child sits beyond the depth limit: it returned 0
+    }
+    if (!returning) {
+        // the walk that just finished answered getColor's intersect() at level fp (scene.cpp:49-60)
+        const float4 q0 = r[0], q2 = r[2];
+        const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+        const uint32_t hit = __float_as_uint(q2.y);
+        if (hit == 0xFFFFFFFFu) { ret = f3(S.bg); returning = true; }
+        else {
+            const bool inside = __float_as_uint(q2.z) != 0;
+            Tri6Regs T = load_tri6(S.tris + hit);
+            const float4 *qm = reinterpret_cast<const float4 *>(S.materials + T.material);
+            const float4 m0 = qm[0], m1 = qm[1];
+            const F3 color = f3(m0.x, m0.y, m0.z), emission = f3(m1.x, m1.y, m1.z);
+            const int kind = (int)__float_as_uint(m1.w);
+            const F3 norma = normalize(inside ? neg(T.n) : T.n);                                // primitives.cpp:81-83,31
+            const F3 x = o + q2.x * d;                                                          // scene.cpp:60
+            if (kind == RT_MAT_DIFFUSE) {
+                const F3 xo = x + epsf * norma;
+                int comp = (int)(rng_u01(rng) * (float)S.n_components);                         // distributions.h:284
+                F3 nd;
+                if (comp == 0) nd = cosine_sample(rng, norma);
+                else {                                                                          // :199-208, :129-141
+                    int li = (int)(rng_u01(rng) * (float)S.n_lights);
+                    Tri6Regs L = load_tri6(S.lights + li);
+                    float u = rng_u01(rng);
+                    float v = rng_u01(rng);
+                    if ((double)(u + v) > 1.) { u = 1 - u; v = 1 - v; }
+                    F3 point = L.a + u * L.b + v * L.c;
+                    nd = normalize(point - xo);
+                }
+                const float dnn = dot(nd, norma);
+                if (dnn < 0) { ret = emission; returning = true; }                              // scene.cpp:64-66
+                else {
+                    const float pdf_cos = smax(0.f, dnn / RT_PI_F);                             // distributions.h:55-58
+                    const bool child_traced = fp + 1 < R.ray_depth;
+                    if (S.n_components == 2 || child_traced) {
+                        if (child_traced) {
+                            const F3 no = x + epsf * nd;                                        // scene.cpp:68
+                            r[0] = make_float4(no.x, no.y, no.z, nd.x);
+                        } else reinterpret_cast<float *>(r)[3] = nd.x;                          // the light query still needs the direction
+                        r[1] = make_float4(nd.y, nd.z, __uint_as_float(rng.x), rng.saved);
+                    }
+                    if (S.n_components == 2) {
+                        // the mixture pdf needs the light sum: walk it (beside the child's trace, when there is one)
+                        r[4] = make_float4(xo.x, xo.y, xo.z, 0.f);
+                        r[5] = make_float4(emission.x, emission.y, emission.z, pdf_cos);
+                        r[6] = make_float4(color.x, color.y, color.z, dnn);
+                        reinterpret_cast<float *>(r + 3)[3] = __uint_as_float(p6_pack(fp, rng.has_saved, sample, P6_PENDING | (child_traced ? 0u : P6_LIGHT_ONLY)));
+                        return P6_LIGHT | (child_traced ? P6_TRACE : 0);
+                    }
+                    // no lights in the scene: the pdf is complete (Mix = {Cosine})
+                    float pdf = 0.f;
+                    pdf += pdf_cos;
+                    pdf = pdf / (float)S.n_components;
+                    const float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)dnn);
+                    float4 *f = r + 8 + 5 * fp;
+                    f[0] = make_float4(emission.x, emission.y, emission.z, __uint_as_float((uint32_t)F6_MUL));
+                    const F3 mult = k * color;
+                    f[1] = make_float4(mult.x, mult.y, mult.z, 0.f);
+                    fp++;
+                    if (child_traced) {
+                        reinterpret_cast<float *>(r + 3)[3] = __uint_as_float(p6_pack(fp, rng.has_saved, sample, 0u));
+                        return P6_TRACE;
+                    }
+                    returning = true;                                                           // ret = 0: the child beyond the depth limit
+                }
+            } else {
+                const F3 dn = normalize(d);
+                const F3 refl = dn - (float)(2. * (double)dot(norma, dn)) * norma;              // scene.cpp:71,75
+                float4 *f = r + 8 + 5 * fp;
+                f[0] = make_float4(emission.x, emission.y, emission.z, __uint_as_float((uint32_t)(kind == RT_MAT_METALLIC ? F6_MUL : F6_DIEL_REFLECT)));
+                f[1] = make_float4(color.x, color.y, color.z, __uint_as_float(inside ? 1u : 0u));
+                f[2] = make_float4(x.x, x.y, x.z, m0.w);
+                f[3] = make_float4(dn.x, dn.y, dn.z, 0.f);
+                f[4] = make_float4(norma.x, norma.y, norma.z, 0.f);
+                fp++;
+                if (fp < R.ray_depth) {
+                    const F3 no = x + epsf * refl;                                              // scene.cpp:72,76
+                    r[0] = make_float4(no.x, no.y, no.z, refl.x);
+                    r[1] = make_float4(refl.y, refl.z, __uint_as_float(rng.x), rng.saved);
+                    reinterpret_cast<float *>(r + 3)[3] = __uint_as_float(p6_pack(fp, rng.has_saved, sample, 0u));
+                    return P6_TRACE;
+                }
+                returning = true;                                                               // recLimit == 0: the child returns 0
+            }
+        }
+    }
+    // unwind: `ret` is the value of the call at level fp (scene.cpp:69,73,77-103)
+    for (;;) {
+        if (fp == 0) { // the camera sample is complete (scene.cpp:111-117)
+            const float4 q3 = r[3];
+            const F3 accum = f3(q3.x, q3.y, q3.z) + ret;
+            sample++;
+            int px, py; bool in_image; size_t out_index;
+            slot_to_pixel(R, slot + W.slot_base, px, py, in_image, out_index);
+            if (sample < (uint32_t)R.samples) {
+                F3 o, d;
+                p6_camera_ray(S, R, rng, px, py, o, d);
+                r[0] = make_float4(o.x, o.y, o.z, d.x);
+                r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
+                r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(p6_pack(0, rng.has_saved, sample, 0u)));
+                return sample < (uint32_t)R.sample_stop ? P6_TRACE : P6_PARKED;
+            }
+            const F3 pxl = R.inv_samples * accum;                                               // scene.cpp:115
+            if (R.out_rgb) { R.out_rgb[3 * out_index] = pxl.x; R.out_rgb[3 * out_index + 1] = pxl.y; R.out_rgb[3 * out_index + 2] = pxl.z; }
+            if (R.out_rgb8) { R.out_rgb8[3 * out_index] = tonemap1(pxl.x); R.out_rgb8[3 * out_index + 1] = tonemap1(pxl.y); R.out_rgb8[3 * out_index + 2] = tonemap1(pxl.z); }
+            return 0;
+        }
+        float4 *f = r + 8 + 5 * (--fp);
+        const float4 f0 = f[0], f1 = f[1];
+        const int fkind = (int)__float_as_uint(f0.w);
+        const F3 emission = f3(f0.x, f0.y, f0.z), fmult = f3(f1.x, f1.y, f1.z);
+        if (fkind == F6_MUL) { ret = emission + fmult * ret; continue; }                        // scene.cpp:69,73
+        const bool finside = __float_as_uint(f1.w) != 0;
+        if (fkind == F6_DIEL_REFRACT) {                                                         // scene.cpp:99-103
+            F3 refracted = ret;
+            if (!finside) refracted = refracted * fmult;
+            ret = emission + refracted;
+            continue;
+        }
+        // F6_DIEL_REFLECT: `ret` is reflectedColor (scene.cpp:77-98)
+        const float4 f2 = f[2], f3q = f[3], f4 = f[4];
+        const F3 fx = f3(f2.x, f2.y, f2.z), fdn = f3(f3q.x, f3q.y, f3q.z), fnorma = f3(f4.x, f4.y, f4.z);
+        float eta1 = 1.f, eta2 = f2.w;
+        if (finside) { float tmp = eta1; eta1 = eta2; eta2 = tmp; }
+        const F3 l = neg(fdn);
+        const float nl = dot(fnorma, l);
+        const float sinTheta2 = (float)((double)(eta1 / eta2) * sqrt((double)(1 - nl * nl)));
+        if (fabs((double)sinTheta2) > 1.) { ret = emission + ret; continue; }
+        const float rr = (eta1 - eta2) / (eta1 + eta2);
+        const float r0 = rr * rr;                                                                // pow(., 2.) == exact square
+        const double om = (double)(1 - nl), om2 = om * om;
+        const float fres = (float)((double)r0 + (double)(1 - r0) * (om2 * om2 * om));            // pow(., 5.)
+        if (rng_u01(rng) < fres) { ret = emission + ret; continue; }
+        const float cosTheta2 = sqrtf(1 - sinTheta2 * sinTheta2);
+        const F3 refr = (eta1 / eta2) * neg(l) + (eta1 / eta2 * nl - cosTheta2) * fnorma;
+        reinterpret_cast<float *>(f)[3] = __uint_as_float((uint32_t)F6_DIEL_REFRACT);
+        fp++;
+        if (fp < R.ray_depth) {
+            const F3 no = fx + epsf * refr;
+            r[0] = make_float4(no.x, no.y, no.z, refr.x);
+            r[1] = make_float4(refr.y, refr.z, __uint_as_float(rng.x), rng.saved);
+            reinterpret_cast<float *>(r + 3)[3] = __uint_as_float(p6_pack(fp, rng.has_saved, sample, 0u));
+            return P6_TRACE;
+        }
+        ret = f3(0.f, 0.f, 0.f);                                                                 // the refracted child beyond the depth limit
+    }
+}
+
+// ---- closest-hit walker over hw6's own tree (closest_hit6 with lane refill) -------------------------------------------------------
+template <bool COUNT>
+RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
+                           const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
+    const int lane = threadIdx.x & 63;
+    bool active = false, refill_ok = true;
+    uint32_t l = 0, slot = 0, cur = 0, hit = 0xFFFFFFFFu, best_ref = 0xFFFFFFFFu, fin = PT_NONE;
+    bool best_inside = false;
+    int sp = 0;
+    F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
+    RayInv ray = make_ray_inv(o, d);
+    float best_t = RT_T_MAX;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+            if (__ballot(fin != PT_NONE)) { // hand-off point (rt_persistent.h)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
+                fin = PT_NONE;
+            }
+            if (!refill_ok) {}
+            else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
+            else if (pt_count(&sh.cnt[PT_Q_TRACE]) > 0) {
+                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                n_queries += __popcll(__ballot(got != PT_NONE));
+                if (got != PT_NONE) {
+                    l = got; slot = pt_slot(sh, l);
+                    const float4 *r = p6_rec(W, slot);
+                    float4 q0 = r[0], q1 = r[1];
+                    o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
+                    ray = make_ray_inv(o, d);
+                    cur = 0; sp = 0; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; best_inside = false;
+                    active = true;
+                }
+            }
+        }
+        const unsigned long long m_active = __ballot(active);
+        if (!m_active) break;
+        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        for (;;) { // phase 1: inner nodes
+            const bool inner = active && !(cur & RT_LEAF_BIT);
+            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (inner) {
+                const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
+                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+                if (COUNT) n_nodes++;
+                float n0, n1;
+                bool h0 = slab_test(lo0, hi0, ray, best_t, n0);
+                bool h1 = slab_test(lo1, hi1, ray, best_t, n1);
+                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+                if (h0 & h1) { bool swap = n1 < n0; stack[sp++][lane] = swap ? c0 : c1; cur = swap ? c1 : c0; }
+                else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp == 0) {
+                    p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), 0.f);
+                    active = false; fin = l;
+                } else cur = stack[--sp][lane];
+            }
+        }
+        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    Tri6Regs T = load_tri6(S.tris + i);
+                    if (COUNT) n_tris++;
+                    float t; bool inside;
+                    // reference tie rule: smallest t, equal t -> lowest index in the reference's figure order
+                    if (tri6_test(T, o, d, t, inside) && (t < best_t || (t == best_t && T.ref_index < best_ref))) {
+                        best_t = t; best_inside = inside; hit = i; best_ref = T.ref_index;
+                    }
+                    if (T.last) break;
+                    i++;
+                }
+            }
+            if (sp == 0) {
+                p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), 0.f);
+                active = false; fin = l;
+            } else cur = stack[--sp][lane];
+        }
+    }
+}
+
+// ---- light-sum walker over the own tree of the lights: no, one or two hits need no order (x + 0 = x, a + b = b + a); more go to
+// the complete light_pdf_sum6_fast (reference association through light_ref) in the slow role -------------------------------------
+template <bool COUNT>
+RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
+                           const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
+    const int lane = threadIdx.x & 63;
+    bool active = false, refill_ok = true, many = false;
+    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE;
+    int sp = 0, k = 0;
+    float term0 = 0.f, term1 = 0.f;
+    F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
+    RayInv ray = make_ray_inv(o, d);
+    auto finish = [&]() {
+        active = false;
+        if (many) { slow = l; return; }
+        const float v = k == 0 ? 0.f : (k == 1 ? term0 : term0 + term1);
+        reinterpret_cast<float *>(p6_rec(W, slot) + 4)[3] = v;
+        fin = l;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+            if (__ballot(fin != PT_NONE || slow != PT_NONE)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE);
+                pt_push(sh, P6_Q_SLOW, slow, slow != PT_NONE);
+                fin = PT_NONE; slow = PT_NONE;
+            }
+            if (!refill_ok) {}
+            else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
+            else if (pt_count(&sh.cnt[PT_Q_LIGHT]) > 0) {
+                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                n_queries += __popcll(__ballot(got != PT_NONE));
+                if (got != PT_NONE) {
+                    l = got; slot = pt_slot(sh, l);
+                    const float4 *r = p6_rec(W, slot);
+                    float4 q0 = r[0], q1 = r[1], q4 = r[4];
+                    o = f3(q4.x, q4.y, q4.z); d = f3(q0.w, q1.x, q1.y);                        // the pdf's ray: x + eps*n towards the sampled direction
+                    ray = make_ray_inv(o, d);
+                    cur = 0; sp = 0; k = 0; many = false; term0 = 0.f; term1 = 0.f;
+                    active = true;
+                }
+            }
+        }
+        const unsigned long long m_active = __ballot(active);
+        if (!m_active) break;
+        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        for (;;) { // phase 1: inner nodes
+            const bool inner = active && !(cur & RT_LEAF_BIT);
+            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (inner) {
+                const float4 *q = reinterpret_cast<const float4 *>(S.fast_light_nodes + cur);
+                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+                if (COUNT) n_nodes++;
+                float n0, n1;
+                bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
+                bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; }
+                else if (h0) cur = c0;
+                else if (h1) cur = c1;
+                else if (sp == 0) finish();
+                else cur = stack[--sp][lane];
+            }
+        }
+        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    Tri6Regs T = load_tri6(S.fast_lights + i);
+                    if (COUNT) n_tris++;
+                    float t; bool inside;
+                    if (tri6_test(T, o, d, t, inside)) {
+                        F3 yn = normalize(inside ? neg(T.n) : T.n);                          // primitives.cpp:31
+                        F3 y = o + t * d;
+                        const float term = T.point_prob * len2(o - y) / fabsf(dot(d, yn));    // distributions.h:116-118
+                        if (k == 0) term0 = term; else if (k == 1) term1 = term; else many = true;
+                        k++;
+                    }
+                    if (T.last) break;
+                    i++;
+                }
+            }
+            if (sp == 0 || many) finish();
+            else cur = stack[--sp][lane];
+        }
+    }
+}
+
+// ---- the kernel (scheduler of rt_persistent.h) ------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S, RenderView R, W6View W, PtParams P) {
+    __shared__ P6Shared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    PtWave wv;
+    wv.n_blocks = gridDim.x; wv.block = blockIdx.x;
+    const uint32_t first_group = P.group_ofs ? P.group_ofs[wv.block] : 0u;
+    const uint32_t n_local_groups = P.group_ofs ? P.group_ofs[wv.block + 1u] - first_group
+                                                : (P.n_groups > wv.block ? (P.n_groups - wv.block + wv.n_blocks - 1u) / wv.n_blocks : 0u);
+    wv.n_local = n_local_groups * 64u;
+    wv.nw = n_local_groups * 2u;
+    if (wv.n_local == 0u) return;
+    for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
+    for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; }
+    for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
+    for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
+    if (tid < 16u) sh.cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) { // seed every pixel, first camera ray (hw6/src/sceneio.cpp:281-284)
+        const uint32_t l = base + tid;
+        bool started = false;
+        if (l < wv.n_local) {
+            const uint32_t slot = pt_slot(sh, l);
+            int x, y; bool inside; size_t out_index;
+            slot_to_pixel(R, slot + W.slot_base, x, y, inside, out_index);
+            if (!inside) {
+                if (R.shard_count > 1) { // padding of a border tile in the compact shard layout
+                    if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
+                    if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
+                }
+            } else if (P.resume) {
+                // a later phase of the frame: the record holds the pixel sum, the random stream and the parked camera ray
+                const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(p6_rec(W, slot) + 3)[3]);
+                started = (packed >> 8) < (uint32_t)R.samples;
+                if (started) atomicOr(&sh.pending[l >> 4], PT_BIT_T << ((l & 15u) * 2u));
+            } else {
+                Rng rng;
+                rng_seed(rng, (uint32_t)(y * R.width + x));
+                F3 o, d;
+                p6_camera_ray(S, R, rng, x, y, o, d);
+                float4 *r = p6_rec(W, slot);
+                r[0] = make_float4(o.x, o.y, o.z, d.x);
+                r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
+                r[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                r[3] = make_float4(0.f, 0.f, 0.f, __uint_as_float(p6_pack(0, rng.has_saved, 0u, 0u)));
+                atomicOr(&sh.pending[l >> 4], PT_BIT_T << ((l & 15u) * 2u));
+                started = true;
+            }
+        }
+        const unsigned long long m = __ballot(started);
+        if (m && lane == 0) atomicAdd(&sh.cnt[PT_N_LIVE], (int)__popcll(m));
+        pt_push(sh, PT_Q_TRACE, l, started);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    uint32_t(*stack)[64] = sh.stack[wave];
+    const int shade_thr = P.shade_thr0 + (int)wave * P.shade_thr_step;
+    uint32_t n_closest = 0, n_light = 0, n_slow = 0;
+    unsigned long long n_nodes = 0, n_tris = 0;
+    uint32_t idle_spins = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { // safety net: never hang the GPU; the host reports the error
+            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
+            break;
+        }
+        const int ns = pt_count(&sh.cnt[PT_Q_SHADE]), nt = pt_count(&sh.cnt[PT_Q_TRACE]), nl = pt_count(&sh.cnt[PT_Q_LIGHT]);
+        if (pt_count(&sh.cnt[P6_Q_SLOW]) > 0) {
+            // light sums with more than two hits: the complete walk with the reference's association, one lane per query
+            uint32_t own_stack[RT6_STACK_SIZE], deep_stack[RT6_STACK_SIZE];
+            const uint32_t got = pt_pop(sh.need[P6_Q_SLOW], &sh.cnt[P6_Q_SLOW], wv.nw, wv.cur[P6_Q_SLOW], true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (got != PT_NONE) {
+                float4 *r = p6_rec(W, pt_slot(sh, got));
+                const float4 q0 = r[0], q1 = r[1], q4 = r[4];
+                const float v = light_pdf_sum6_fast(S, f3(q4.x, q4.y, q4.z), f3(q0.w, q1.x, q1.y), own_stack, deep_stack);
+                reinterpret_cast<float *>(r + 4)[3] = v;
+            }
+            n_slow += __popcll(__ballot(got != PT_NONE));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
+            idle_spins = 0;
+            continue;
+        }
+        if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
+            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            int todo = 0;
+            if (got != PT_NONE) todo = p6_advance(S, R, W, pt_slot(sh, got));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const bool tr = got != PT_NONE && (todo & P6_TRACE), li = got != PT_NONE && (todo & P6_LIGHT);
+            if (tr || li) atomicOr(&sh.pending[got >> 4], ((tr ? PT_BIT_T : 0u) | (li ? PT_BIT_L : 0u)) << ((got & 15u) * 2u));
+            pt_push(sh, PT_Q_TRACE, got, tr);
+            pt_push(sh, PT_Q_LIGHT, got, li);
+            if (got != PT_NONE) atomicAdd(&sh.cost[got >> 6], 1u);
+            const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == P6_PARKED));
+            if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
+            idle_spins = 0;
+            continue;
+        }
+        if (nt + nl > 0) {
+            const long long wt = (long long)nt * P.cost_t * (pt_count(&sh.cnt[PT_W_LIGHT]) + 1), wl = (long long)nl * P.cost_l * (pt_count(&sh.cnt[PT_W_TRACE]) + 1);
+            if (nl == 0 || (nt > 0 && wt >= wl)) {
+                if (lane == 0) atomicAdd(&sh.cnt[PT_W_TRACE], 1);
+                p6_trace_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_closest, n_nodes, n_tris);
+                if (lane == 0) atomicSub(&sh.cnt[PT_W_TRACE], 1);
+            } else {
+                if (lane == 0) atomicAdd(&sh.cnt[PT_W_LIGHT], 1);
+                p6_light_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_light, n_nodes, n_tris);
+                if (lane == 0) atomicSub(&sh.cnt[PT_W_LIGHT], 1);
+            }
+            idle_spins = 0;
+            continue;
+        }
+        if (pt_count(&sh.cnt[PT_N_LIVE]) <= 0) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (++idle_spins > (1u << 24)) {
+            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
+            break;
+        }
+    }
+    if (P.group_cost) { // every wave leaves the loop once the workgroup's pixels are done (or at the deadline)
+        __syncthreads();
+        for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
+    }
+    if (lane == 0 && P.counters) {
+        if (n_closest) atomicAdd(&P.counters[0], (unsigned long long)n_closest);
+        if (n_light) atomicAdd(&P.counters[1], (unsigned long long)n_light);
+        if (n_slow) atomicAdd(&P.counters[13], (unsigned long long)n_slow);
+    }
+    if (COUNT && P.counters) { atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris); }
+}
+
+} // namespace dev
+} // namespace rtamd

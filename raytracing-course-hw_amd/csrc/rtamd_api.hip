@@ -19,6 +19,7 @@
 #include "device/rt_wavefront.h"
 #include "device/rt_persistent.h"
 #include "device/rt_kernels_hw6.h"
+#include "device/rt_persistent_hw6.h"
 #include "device/rt_kernels_txt.h"
 #include "device/rt_kernels_hw2.h"
 #include "device/rt_kernels_hw4.h"
@@ -108,6 +109,8 @@ struct rt_scene {
     size_t pt_slots = 0, pt_levels = 0, pt_group_words = 0;
     uint32_t pt_passes = 0, pt_blocks = 0, pt_launches = 0;
     double pt_rebalance_ms = 0, pt_imbalance = 0;
+    float4 *pt6_r0 = nullptr;        // hw6 persistent pipeline: path records (frames included) of one pass
+    size_t pt6_slots = 0;
     int pipeline = 0;                // RT_PIPELINE_* of the last render
     void free_wf() {
         for (void *p : wf_allocs) (void)hipFree(p);
@@ -120,6 +123,7 @@ struct rt_scene {
         if (d_partial) (void)hipFree(d_partial);
         if (pt_r0) (void)hipFree(pt_r0);
         if (pt_groups) (void)hipFree(pt_groups);
+        if (pt6_r0) (void)hipFree(pt6_r0);
         if (d_pt_debug) (void)hipFree(d_pt_debug);
         for (void *p : allocations) (void)hipFree(p);
         if (ev_start) (void)hipEventDestroy(ev_start);
@@ -542,6 +546,46 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
         }
 }
 
+// Between the two phases of a persistent render: read the hits every workgroup shaded per 8x8 sub-tile in the first phase and deal the
+// sub-tiles again, longest processing time first onto the least loaded workgroup (at most groups_per_block each); the lists go to
+// d_ofs / d_ids for the second launch.
+static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_ofs, uint32_t *d_ids, uint32_t groups, uint32_t blocks, uint32_t groups_per_block, hipStream_t stream) {
+    std::vector<uint32_t> cost(groups), ofs, ids, order(groups);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const double t0 = now_ms();
+    HIP_CHECK(hipMemcpy(cost.data(), d_cost, (size_t)groups * 4, hipMemcpyDeviceToHost));
+    for (uint32_t g = 0; g < groups; g++) order[g] = g;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
+    std::vector<std::pair<uint64_t, uint32_t>> heap; // (load, block), min-heap
+    heap.reserve(blocks);
+    for (uint32_t b = 0; b < blocks; b++) heap.push_back({0ull, b});
+    auto cmp = [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    std::vector<std::vector<uint32_t>> mine(blocks);
+    uint64_t total = 0, before_max = 0;
+    { std::vector<uint64_t> rr(blocks, 0); for (uint32_t g = 0; g < groups; g++) { rr[g % blocks] += cost[g]; total += cost[g]; } for (uint64_t v : rr) before_max = v > before_max ? v : before_max; }
+    for (uint32_t g : order) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        auto &top = heap.back();
+        mine[top.second].push_back(g);
+        top.first += (uint64_t)cost[g] + 1u; // + 1: empty sub-tiles (padding) are spread evenly too
+        if (mine[top.second].size() >= groups_per_block) heap.pop_back(); // full: out of the deal
+        else std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    ofs.assign(blocks + 1, 0);
+    for (uint32_t b = 0; b < blocks; b++) {
+        std::sort(mine[b].begin(), mine[b].end());
+        ofs[b] = (uint32_t)ids.size();
+        ids.insert(ids.end(), mine[b].begin(), mine[b].end());
+    }
+    ofs[blocks] = (uint32_t)ids.size();
+    HIP_CHECK(hipMemcpyAsync(d_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream)); // the vectors go out of scope
+    scene->pt_rebalance_ms += now_ms() - t0;
+    if (total) scene->pt_imbalance = (double)before_max * blocks / (double)total; // slowest workgroup / mean under the round-robin deal
+}
+
 // Persistent dataflow driver (device/rt_persistent.h): ONE launch renders up to n_cus x PT_MAX_PATHS path slots; larger frames
 // (or throughput mode with many streams) take several passes over disjoint slot ranges, each a complete render of its pixels.
 //
@@ -600,7 +644,6 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     W.stride = 4u + 2u * (uint32_t)scene->pt_levels;
     uint32_t first = 0, launch = 0;
     scene->pt_blocks = 0; scene->pt_rebalance_ms = 0; scene->pt_imbalance = 0;
-    std::vector<uint32_t> cost, ofs, ids, order;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t groups = n_work - first < pass_groups ? n_work - first : pass_groups;
         W.n_slots = groups * 64u;
@@ -615,44 +658,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
             P.group_cost = (two_phase && ph == 0) ? d_cost : nullptr;
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
-            if (ph == 1) { // re-deal: longest processing time first onto the least loaded workgroup (at most groups_per_block each)
-                cost.resize(groups);
-                HIP_CHECK(hipStreamSynchronize(stream));
-                const double t0 = now_ms();
-                HIP_CHECK(hipMemcpy(cost.data(), d_cost, (size_t)groups * 4, hipMemcpyDeviceToHost));
-                order.resize(groups);
-                for (uint32_t g = 0; g < groups; g++) order[g] = g;
-                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
-                std::vector<std::pair<uint64_t, uint32_t>> heap; // (load, block), min-heap
-                heap.reserve(blocks);
-                for (uint32_t b = 0; b < blocks; b++) heap.push_back({0ull, b});
-                auto cmp = [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a > b; };
-                std::make_heap(heap.begin(), heap.end(), cmp);
-                std::vector<std::vector<uint32_t>> mine(blocks);
-                uint64_t total = 0, before_max = 0;
-                { std::vector<uint64_t> rr(blocks, 0); for (uint32_t g = 0; g < groups; g++) { rr[g % blocks] += cost[g]; total += cost[g]; } for (uint64_t v : rr) before_max = v > before_max ? v : before_max; }
-                for (uint32_t g : order) {
-                    std::pop_heap(heap.begin(), heap.end(), cmp);
-                    auto &top = heap.back();
-                    mine[top.second].push_back(g);
-                    top.first += (uint64_t)cost[g] + 1u; // + 1: empty sub-tiles (padding) are spread evenly too
-                    if (mine[top.second].size() >= groups_per_block) heap.pop_back(); // full: out of the deal
-                    else std::push_heap(heap.begin(), heap.end(), cmp);
-                }
-                ofs.assign(blocks + 1, 0);
-                ids.clear();
-                for (uint32_t b = 0; b < blocks; b++) {
-                    std::sort(mine[b].begin(), mine[b].end());
-                    ofs[b] = (uint32_t)ids.size();
-                    ids.insert(ids.end(), mine[b].begin(), mine[b].end());
-                }
-                ofs[blocks] = (uint32_t)ids.size();
-                HIP_CHECK(hipMemcpyAsync(d_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, stream));
-                HIP_CHECK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, stream));
-                HIP_CHECK(hipStreamSynchronize(stream)); // the vectors are reused by the next pass
-                scene->pt_rebalance_ms += now_ms() - t0;
-                if (total) scene->pt_imbalance = (double)before_max * blocks / (double)total; // slowest workgroup / mean under the round-robin deal
-            }
+            if (ph == 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             // kernel variant by the features this render can reach (fewer features, fewer spilled registers): the hw7 integrator has no
@@ -668,6 +674,75 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
                 else if (feat == WF_FEAT_ENV) hipLaunchKernelGGL((dev::pt_persistent_kernel<false, WF_FEAT_ENV>), grid, block, 0, stream, V, Rp, W, P);
                 else hipLaunchKernelGGL((dev::pt_persistent_kernel<false, 0>), grid, block, 0, stream, V, Rp, W, P);
             }
+            if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch + 1], stream));
+            launch++;
+        }
+        first += groups;
+    }
+    HIP_CHECK(hipGetLastError());
+    scene->pt_passes = passes;
+    scene->pt_launches = launch;
+}
+
+// hw6 in the persistent organisation (device/rt_persistent_hw6.h): passes of up to n_cus x P6_MAX_PATHS path slots, each rendered in
+// two phases with a re-deal of the sub-tiles in between like launch_persistent — here the cost of a pixel spans 1 to 63 walks per
+// sample (a wall against the glass bunny), so the deal matters far more than for hw8.
+static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
+    auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
+    const uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus);
+    const uint32_t groups_per_block = P6_MAX_PATHS / 64;
+    const uint64_t pass_cap = (uint64_t)n_blocks_max * groups_per_block;
+    const uint32_t passes = (uint32_t)((n_work + pass_cap - 1) / pass_cap);
+    const uint32_t pass_groups = (n_work + passes - 1) / passes;
+    const size_t n_slots = (size_t)pass_groups * 64;
+    if (scene->pt6_slots < n_slots) {
+        if (scene->pt6_r0) (void)hipFree(scene->pt6_r0);
+        scene->pt6_r0 = nullptr; scene->pt6_slots = 0;
+        HIP_CHECK(hipMalloc((void **)&scene->pt6_r0, n_slots * (size_t)P6_REC * sizeof(float4)));
+        scene->pt6_slots = n_slots;
+    }
+    const size_t group_words = 2 * (size_t)pass_groups + n_blocks_max + 1;
+    if (scene->pt_group_words < group_words) {
+        if (scene->pt_groups) (void)hipFree(scene->pt_groups);
+        scene->pt_groups = nullptr; scene->pt_group_words = 0;
+        HIP_CHECK(hipMalloc((void **)&scene->pt_groups, group_words * 4));
+        scene->pt_group_words = group_words;
+    }
+    uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + pass_groups, *d_ids = d_ofs + n_blocks_max + 1;
+    dev::PtParams P{};
+    const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
+    P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL);
+    P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
+    P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);
+    P.cost_t = 1; P.cost_l = 1;
+    P.counters = scene->d_counters;
+    P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
+    const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
+    const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
+    const uint32_t phases = two_phase ? 2u : 1u;
+    if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes * phases) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
+    dev::W6View W{};
+    W.r0 = scene->pt6_r0;
+    uint32_t first = 0, launch = 0;
+    scene->pt_rebalance_ms = 0; scene->pt_imbalance = 0; scene->pt_blocks = 0;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t groups = n_work - first < pass_groups ? n_work - first : pass_groups;
+        W.slot_base = first * 64u;
+        P.n_groups = groups;
+        const uint32_t blocks = groups < n_blocks_max ? groups : n_blocks_max;
+        if (blocks > scene->pt_blocks) scene->pt_blocks = blocks;
+        for (uint32_t ph = 0; ph < phases; ph++) {
+            RenderView Rp = R;
+            Rp.sample_stop = (two_phase && ph == 0) ? phase0 : R.samples;
+            P.resume = ph;
+            P.group_cost = (two_phase && ph == 0) ? d_cost : nullptr;
+            P.group_ofs = ph ? d_ofs : nullptr;
+            P.group_ids = ph ? d_ids : nullptr;
+            if (ph == 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
+            if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
+            if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
+            else hipLaunchKernelGGL(dev::p6_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch + 1], stream));
             launch++;
         }
@@ -773,7 +848,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (hw7) { V8.hw7 = 1; V8.last_level_emission_only = 0; V8.env_image = -1; }
         if (!use_persistent && !getenv("RTAMD_ROUNDS_EXACT")) V8.exact_boxes = 0; // round pipeline and megakernel: the padded box test's answer stands
         uint32_t launches = 0;
-        bool time_trace = false;
+        bool time_trace = false, use_persistent6 = false;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
             if (use_wavefront) {
@@ -829,6 +904,12 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 hipLaunchKernelGGL(dev::render_hw3_kernel, dim3(blocks), dim3(64), 0, stream, scene->viewt, R, txt_tan_fov_y, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
+            } else if (scene->flavor == RT_INTEGRATOR_HW6 && scene->hw6_lds_stack && !(ksel && strcmp(ksel, "mega") == 0) && !getenv("RTAMD_HW6_SCRATCH_STACK")) {
+                // persistent dataflow organisation (device/rt_persistent_hw6.h); RTAMD_KERNEL=mega keeps the per-lane path machine
+                use_persistent6 = true;
+                time_trace = stats != nullptr;
+                launch_persistent6(scene, scene->view6, R, n_work, stream, count, time_trace);
+                launches = scene->pt_launches;
             } else if (scene->flavor == RT_INTEGRATOR_HW6) {
                 if (scene->hw6_lds_stack && !getenv("RTAMD_HW6_SCRATCH_STACK")) hipLaunchKernelGGL(dev::render_hw6_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
                 else hipLaunchKernelGGL(dev::render_hw6_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
@@ -848,7 +929,11 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 512, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         use_persistent = use_persistent && use_wavefront && blocks;
-        scene->pipeline = use_persistent ? RT_PIPELINE_PERSISTENT : (use_wavefront && blocks ? RT_PIPELINE_ROUNDS : RT_PIPELINE_SINGLE);
+        if (use_persistent6 && getenv("RTAMD_DEBUG_COUNTERS"))
+            fprintf(stderr, "[rtamd] persistent hw6 pipeline: %u launches; re-deal %.2f ms on the host (slowest workgroup / mean under the round-robin deal: %.3f); light sums through the slow role %llu of %llu\n",
+                    scene->pt_launches, scene->pt_rebalance_ms, scene->pt_imbalance, h_cnt[13], h_cnt[1]);
+        if (use_persistent6 && h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent hw6 kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");
+        scene->pipeline = (use_persistent || use_persistent6) ? RT_PIPELINE_PERSISTENT : (use_wavefront && blocks ? RT_PIPELINE_ROUNDS : RT_PIPELINE_SINGLE);
         if (use_persistent) {
             if (h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");
             h_cnt[0] -= h_cnt[10] < h_cnt[0] ? h_cnt[10] : h_cnt[0]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
@@ -903,7 +988,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
             stats->pipeline = (uint32_t)scene->pipeline;
-            if (use_persistent) {
+            if (use_persistent || use_persistent6) {
                 double sum = 0;
                 for (uint32_t pp = 0; time_trace && pp < scene->pt_launches; pp++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * pp], scene->ev_pool[2 * pp + 1])); sum += e; }
                 stats->dominant_kernel_ms = time_trace ? sum : ms; stats->dominant_kernel_launches = scene->pt_launches;

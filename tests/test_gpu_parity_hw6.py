@@ -17,17 +17,42 @@ def _cmp(tag, rgb, ref, rgb8, ref8):
     return rmse, bad
 
 
+@pytest.mark.parametrize("kernel", ["persistent", "mega"])
 @pytest.mark.parametrize("name,w,h,spp", [("practice6_1", 64, 48, 6), ("hw6_soup", 64, 48, 8), ("practice6_2", 40, 40, 4)])
-def test_hw6_scene_matches_oracle(rt, name, w, h, spp):
+def test_hw6_scene_matches_oracle(rt, monkeypatch, name, w, h, spp, kernel):
+    """Both organisations of the hw6 integrator: the persistent dataflow pipeline (default: path frames in HBM records, walkers that
+    refill, a shader role that runs the frame machine between walks) and the per-lane path machine (RTAMD_KERNEL=mega)."""
+    monkeypatch.setenv("RTAMD_KERNEL", kernel)
     sd = pin_cases.HW6_CASES[name][0]()
     scene = rt.Scene(sd)
     assert np.array_equal(scene.light_order(), oracle_lib.Hw6Oracle(sd).light_order())
-    rgb, rgb8, st = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6)
+    rgb, rgb8, st = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6, counters=True)
     ref, ref8, _ = oracle_lib.Hw6Oracle(sd).render(w, h, spp)
-    rmse, bad = _cmp(f"hw6 {name} {w}x{h}x{spp}", rgb, ref, rgb8, ref8)
+    rmse, bad = _cmp(f"hw6 {name}[{kernel}] {w}x{h}x{spp} (pipeline {st.pipeline}, {st.closest_hit_queries}+{st.light_pdf_queries} queries)", rgb, ref, rgb8, ref8)
     assert ref.mean() > 0.01
     assert rmse < RMSE_TOL and bad <= max(1, w * h // 1000)
+    assert st.pipeline == (rt.RT_PIPELINE_PERSISTENT if kernel == "persistent" else rt.RT_PIPELINE_SINGLE) and st.closest_hit_queries > w * h * spp
     scene.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 8])
+def test_hw6_ray_depths_and_shards_persistent_equals_path_machine(rt, monkeypatch, depth):
+    """Depth limits cut the recursion tree at every kind of frame (a DIFFUSE bounce whose child lies beyond the limit still needs its
+    light-pdf sum; dielectric reflect / refract children return 0 there), and shards use the compact layout: the two organisations
+    must agree bit for bit, and with the oracle."""
+    sd = pin_cases.load_hw6("practice6_1")
+    scene = rt.Scene(sd)
+    monkeypatch.setenv("RTAMD_KERNEL", "mega")
+    a, a8, _ = scene.render(72, 56, 5, integrator=rt.RT_INTEGRATOR_HW6, ray_depth=depth)
+    sa, _, _ = scene.render(72, 56, 5, integrator=rt.RT_INTEGRATOR_HW6, ray_depth=depth, shard_index=1, shard_count=3, tile=16)
+    monkeypatch.setenv("RTAMD_KERNEL", "persistent")
+    b, b8, st = scene.render(72, 56, 5, integrator=rt.RT_INTEGRATOR_HW6, ray_depth=depth)
+    sb, _, _ = scene.render(72, 56, 5, integrator=rt.RT_INTEGRATOR_HW6, ray_depth=depth, shard_index=1, shard_count=3, tile=16)
+    scene.close()
+    assert st.pipeline == rt.RT_PIPELINE_PERSISTENT
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a8, b8) and np.array_equal(sa, sb, equal_nan=True)
+    ref, _, _ = oracle_lib.Hw6Oracle(sd).render(72, 56, 5, ray_depth=depth)
+    assert np.array_equal(b, ref, equal_nan=True)
 
 
 def test_hw6_scene_rejects_wrong_integrator(rt):

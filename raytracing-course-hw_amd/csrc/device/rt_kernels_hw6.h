@@ -164,6 +164,43 @@ RT_DEV float light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
 // added in the reference's association by walking the reference tree's index ranges only where hits lie: sum(node) =
 // sum(left) + sum(right), a side without hits contributes the additive identity, a leaf adds its hits in index order.
 #define RT6_MAX_LIGHT_HITS 16
+// step (3): the hits of one query (reference light index, term), at most RT6_MAX_LIGHT_HITS, added in the reference's association
+RT_DEV float light_sum6_associate(const SceneView6 &S, uint32_t *hit_idx, float *hit_term, int k) {
+    for (int i = 1; i < k; i++) { // insertion sort by the reference's light index
+        uint32_t id = hit_idx[i]; float tm = hit_term[i];
+        int j = i - 1;
+        while (j >= 0 && hit_idx[j] > id) { hit_idx[j + 1] = hit_idx[j]; hit_term[j + 1] = hit_term[j]; j--; }
+        hit_idx[j + 1] = id; hit_term[j + 1] = tm;
+    }
+    // frames: a postponed right side {node, lo, hi} (kind 0) or a finished left total waiting for its right side (kind 1)
+    uint32_t f_node[RT6_MAX_LIGHT_HITS]; int f_lo[RT6_MAX_LIGHT_HITS], f_hi[RT6_MAX_LIGHT_HITS]; float f_val[RT6_MAX_LIGHT_HITS]; uint32_t f_add = 0;
+    int fsp = 0;
+    uint32_t node = 0; int lo = 0, hi = k;
+    float v = 0.f;
+    for (;;) {
+        for (;;) { // total of hits [lo, hi) under `node`
+            uint4 n = reinterpret_cast<const uint4 *>(S.light_ref)[node];
+            if (n.x == 0) { v = 0.f; for (int j = lo; j < hi; j++) v += hit_term[j]; break; }   // leaf: sequential, index order
+            uint32_t right_first = S.light_ref[4 * n.y + 2];
+            int m = lo;
+            while (m < hi && hit_idx[m] < right_first) m++;
+            if (m == lo) { node = n.y; continue; }        // nothing on the left:  0 + right
+            if (m == hi) { node = n.x; continue; }        // nothing on the right: left + 0
+            f_node[fsp] = n.y; f_lo[fsp] = m; f_hi[fsp] = hi; f_add &= ~(1u << fsp); fsp++;
+            node = n.x; hi = m;
+        }
+        for (;;) { // fold finished totals, or open the next postponed right side
+            if (fsp == 0) return v;
+            fsp--;
+            if ((f_add >> fsp) & 1u) { v = f_val[fsp] + v; continue; }                              // left total + right total
+            node = f_node[fsp]; lo = f_lo[fsp]; hi = f_hi[fsp];
+            f_val[fsp] = v; f_add |= 1u << fsp; fsp++;
+            break;
+        }
+    }
+}
+
+
 RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stack, uint32_t *deep_stack) {
     RayInv ray = make_ray_inv(x, d);
     int sp = 0, k = 0;
@@ -218,38 +255,7 @@ RT_DEV float light_pdf_sum6_fast(const SceneView6 &S, F3 x, F3 d, uint32_t *stac
     if (k == 0) return 0.f;
     if (k == 1) return hit_term[0];
     if (k == 2) return hit_term[0] + hit_term[1];
-    for (int i = 1; i < k; i++) { // insertion sort by the reference's light index
-        uint32_t id = hit_idx[i]; float tm = hit_term[i];
-        int j = i - 1;
-        while (j >= 0 && hit_idx[j] > id) { hit_idx[j + 1] = hit_idx[j]; hit_term[j + 1] = hit_term[j]; j--; }
-        hit_idx[j + 1] = id; hit_term[j + 1] = tm;
-    }
-    // frames: a postponed right side {node, lo, hi} (kind 0) or a finished left total waiting for its right side (kind 1)
-    uint32_t f_node[RT6_MAX_LIGHT_HITS]; int f_lo[RT6_MAX_LIGHT_HITS], f_hi[RT6_MAX_LIGHT_HITS]; float f_val[RT6_MAX_LIGHT_HITS]; uint32_t f_add = 0;
-    int fsp = 0;
-    uint32_t node = 0; int lo = 0, hi = k;
-    float v = 0.f;
-    for (;;) {
-        for (;;) { // total of hits [lo, hi) under `node`
-            uint4 n = reinterpret_cast<const uint4 *>(S.light_ref)[node];
-            if (n.x == 0) { v = 0.f; for (int j = lo; j < hi; j++) v += hit_term[j]; break; }   // leaf: sequential, index order
-            uint32_t right_first = S.light_ref[4 * n.y + 2];
-            int m = lo;
-            while (m < hi && hit_idx[m] < right_first) m++;
-            if (m == lo) { node = n.y; continue; }        // nothing on the left:  0 + right
-            if (m == hi) { node = n.x; continue; }        // nothing on the right: left + 0
-            f_node[fsp] = n.y; f_lo[fsp] = m; f_hi[fsp] = hi; f_add &= ~(1u << fsp); fsp++;
-            node = n.x; hi = m;
-        }
-        for (;;) { // fold finished totals, or open the next postponed right side
-            if (fsp == 0) return v;
-            fsp--;
-            if ((f_add >> fsp) & 1u) { v = f_val[fsp] + v; continue; }                              // left total + right total
-            node = f_node[fsp]; lo = f_lo[fsp]; hi = f_hi[fsp];
-            f_val[fsp] = v; f_add |= 1u << fsp; fsp++;
-            break;
-        }
-    }
+    return light_sum6_associate(S, hit_idx, hit_term, k);
 }
 
 enum { F6_MUL = 0, F6_DIEL_REFLECT = 1, F6_DIEL_REFRACT = 2 };

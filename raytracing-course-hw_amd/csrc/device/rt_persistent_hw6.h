@@ -26,10 +26,12 @@ namespace dev {
 #define P6_MAX_PATHS 8192            // paths per workgroup: with 36-entry stacks the bitmaps get 8 KB
 #define P6_NW (P6_MAX_PATHS / 32)
 #define P6_Q_SLOW 3                  // light sums with more than two hits: the complete per-lane light_pdf_sum6_fast
-#define P6_REC 48u                   // float4 per path record: 8 + 5 per frame x RT6_MAX_DEPTH
+#define P6_REC 56u                   // float4 per path record: 8 + 5 per frame x RT6_MAX_DEPTH + 8 for the hits of a light sum
 // record: r0 = o.xyz d.x | r1 = d.yz rng.x rng.saved | r2 = hit t, figure slot, inside, - | r3 = accum.xyz packed
 //         r4 = light-query origin xo.xyz, light sum (raw)  | r5 = pending emission.xyz, cosine pdf | r6 = pending colour.xyz, d.n
+//         r7 = number of lights the pdf's ray hit (when more than two), -, -, -
 //         frame f at r[8 + 5 f]: emission.xyz kind | mult.xyz inside | x.xyz ior | dn.xyz - | norma.xyz -
+//         r[48..55]: up to 16 hits of the light sum {reference light index, term}, for the slow role
 // packed: fp:4 | has_saved:16 | pending:32 | light_only:64 (the pending bounce's child is beyond the depth limit: no trace) | sample << 8
 #define P6_PENDING 32u
 #define P6_LIGHT_ONLY 64u
@@ -318,21 +320,21 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     }
 }
 
-// ---- light-sum walker over the own tree of the lights: no, one or two hits need no order (x + 0 = x, a + b = b + a); more go to
-// the complete light_pdf_sum6_fast (reference association through light_ref) in the slow role -------------------------------------
+// ---- light-sum walker over the own tree of the lights: no, one or two hits need no order (x + 0 = x, a + b = b + a); more are
+// left in the record and added in the reference's association (light_sum6_associate) by the slow role -----------------------------
 template <bool COUNT>
 RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
     const int lane = threadIdx.x & 63;
     bool active = false, refill_ok = true, many = false;
-    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE;
+    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE, idx0 = 0, idx1 = 0;
     int sp = 0, k = 0;
     float term0 = 0.f, term1 = 0.f;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
-        if (many) { slow = l; return; }
+        if (many) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k; slow = l; return; }
         const float v = k == 0 ? 0.f : (k == 1 ? term0 : term0 + term1);
         reinterpret_cast<float *>(p6_rec(W, slot) + 4)[3] = v;
         fin = l;
@@ -395,17 +397,64 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                         F3 yn = normalize(inside ? neg(T.n) : T.n);                          // primitives.cpp:31
                         F3 y = o + t * d;
                         const float term = T.point_prob * len2(o - y) / fabsf(dot(d, yn));    // distributions.h:116-118
-                        if (k == 0) term0 = term; else if (k == 1) term1 = term; else many = true;
+                        if (k == 0) { term0 = term; idx0 = T.ref_index; }
+                        else if (k == 1) { term1 = term; idx1 = T.ref_index; }
+                        else {
+                            float2 *h = reinterpret_cast<float2 *>(p6_rec(W, slot) + 48);
+                            if (k == 2) { h[0] = make_float2(__uint_as_float(idx0), term0); h[1] = make_float2(__uint_as_float(idx1), term1); }
+                            if (k < RT6_MAX_LIGHT_HITS) h[k] = make_float2(__uint_as_float(T.ref_index), term);
+                            many = true;
+                        }
                         k++;
                     }
                     if (T.last) break;
                     i++;
                 }
             }
-            if (sp == 0 || many) finish();
+            if (sp == 0 || k > RT6_MAX_LIGHT_HITS) finish();
             else cur = stack[--sp][lane];
         }
     }
+}
+
+// ---- slow role: three or more hits, added in the reference's association.  sum(node) = sum(left) + sum(right) with a side without
+// hits as the additive identity means: of the hits sorted by reference light index, those two neighbouring groups are added first
+// that separate deepest in the reference tree (SceneView6::light_sep; inside a leaf the pseudo depths give ((a + b) + c)).  That is
+// an operator-precedence evaluation with the separation depth as the precedence, done in place in the lane's LDS stack column:
+// words 0..15 hold the terms and then the value stack, words 16..31 the light indices and then the depth stack. ---------------------
+RT_DEV float p6_merge_hits(const SceneView6 &S, const float2 *h, int k, uint32_t (*col)[64]) {
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < k; i++) { // insertion sort by the reference's light index
+        const float2 e = h[i];
+        const uint32_t id = __float_as_uint(e.x);
+        int j = i - 1;
+        while (j >= 0 && col[16 + j][lane] > id) { col[17 + j][lane] = col[16 + j][lane]; col[j + 1][lane] = col[j][lane]; j--; }
+        col[17 + j][lane] = id; col[j + 1][lane] = __float_as_uint(e.y);
+    }
+    const uint32_t nl = S.n_lights;
+    int vs = 1, os = 0;                                   // value stack: words 0..vs-1; depth stack: words 16..16+os-1
+    uint32_t prev = col[16][lane];
+    for (int i = 1; i < k; i++) {
+        const uint32_t id = col[16 + i][lane];
+        const float term = __uint_as_float(col[i][lane]);
+        const uint32_t len = id - prev, lv = 31u - (uint32_t)__clz((int)len);
+        const uint16_t m0 = S.light_sep[(size_t)lv * nl + prev], m1 = S.light_sep[(size_t)lv * nl + (id - (1u << lv))];
+        const uint32_t depth = m0 < m1 ? m0 : m1;          // where the hits prev and id separate
+        while (os > 0 && col[15 + os][lane] > depth) {     // the groups on the stack that separate deeper are complete: fold them
+            const float b = __uint_as_float(col[vs - 1][lane]), a = __uint_as_float(col[vs - 2][lane]);
+            col[vs - 2][lane] = __float_as_uint(a + b);
+            vs--; os--;
+        }
+        col[16 + os][lane] = depth; os++;
+        col[vs][lane] = __float_as_uint(term); vs++;
+        prev = id;
+    }
+    while (os > 0) {
+        const float b = __uint_as_float(col[vs - 1][lane]), a = __uint_as_float(col[vs - 2][lane]);
+        col[vs - 2][lane] = __float_as_uint(a + b);
+        vs--; os--;
+    }
+    return __uint_as_float(col[0][lane]);
 }
 
 // ---- the kernel (scheduler of rt_persistent.h) ------------------------------------------------------------------------------------------
@@ -426,6 +475,7 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
     for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
     for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
     if (tid < 16u) sh.cnt[tid] = 0;
+    if (P.debug && tid == 0) { P.debug[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); P.debug[3 * blockIdx.x + 2] = wv.n_local; }
     __syncthreads();
     for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) { // seed every pixel, first camera ray (hw6/src/sceneio.cpp:281-284)
         const uint32_t l = base + tid;
@@ -472,6 +522,8 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
     unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t idle_spins = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_role[5] = {0, 0, 0, 0, 0}, t_mark = t_start; // COUNT: wave time as closest-hit walker, light walker, shader, slow light sums, idle
+    auto clock_role = [&](int role) { if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_role[role] += now - t_mark; t_mark = now; } };
     for (;;) {
         if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { // safety net: never hang the GPU; the host reports the error
             if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
@@ -479,20 +531,28 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
         }
         const int ns = pt_count(&sh.cnt[PT_Q_SHADE]), nt = pt_count(&sh.cnt[PT_Q_TRACE]), nl = pt_count(&sh.cnt[PT_Q_LIGHT]);
         if (pt_count(&sh.cnt[P6_Q_SLOW]) > 0) {
-            // light sums with more than two hits: the complete walk with the reference's association, one lane per query
-            uint32_t own_stack[RT6_STACK_SIZE], deep_stack[RT6_STACK_SIZE];
+            // light sums with more than two hits: the reference's association over the hits the walker left in the record, one lane
+            // per query (more than 16 hits: the plain reference-order walk)
+            uint32_t deep_stack[RT6_STACK_SIZE];
             const uint32_t got = pt_pop(sh.need[P6_Q_SLOW], &sh.cnt[P6_Q_SLOW], wv.nw, wv.cur[P6_Q_SLOW], true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (got != PT_NONE) {
                 float4 *r = p6_rec(W, pt_slot(sh, got));
-                const float4 q0 = r[0], q1 = r[1], q4 = r[4];
-                const float v = light_pdf_sum6_fast(S, f3(q4.x, q4.y, q4.z), f3(q0.w, q1.x, q1.y), own_stack, deep_stack);
+                const int k = (int)reinterpret_cast<const uint32_t *>(r + 7)[0];
+                float v;
+                if (k > RT6_MAX_LIGHT_HITS) {
+                    const float4 q0 = r[0], q1 = r[1], q4 = r[4];
+                    v = light_pdf_sum6(S, f3(q4.x, q4.y, q4.z), f3(q0.w, q1.x, q1.y), deep_stack);
+                } else {
+                    v = p6_merge_hits(S, reinterpret_cast<const float2 *>(r + 48), k, stack);
+                }
                 reinterpret_cast<float *>(r + 4)[3] = v;
             }
             n_slow += __popcll(__ballot(got != PT_NONE));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
             idle_spins = 0;
+            clock_role(3);
             continue;
         }
         if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
@@ -509,6 +569,7 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
             const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == P6_PARKED));
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;
+            clock_role(2);
             continue;
         }
         if (nt + nl > 0) {
@@ -517,16 +578,19 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
                 if (lane == 0) atomicAdd(&sh.cnt[PT_W_TRACE], 1);
                 p6_trace_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_closest, n_nodes, n_tris);
                 if (lane == 0) atomicSub(&sh.cnt[PT_W_TRACE], 1);
+                clock_role(0);
             } else {
                 if (lane == 0) atomicAdd(&sh.cnt[PT_W_LIGHT], 1);
                 p6_light_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_light, n_nodes, n_tris);
                 if (lane == 0) atomicSub(&sh.cnt[PT_W_LIGHT], 1);
+                clock_role(1);
             }
             idle_spins = 0;
             continue;
         }
         if (pt_count(&sh.cnt[PT_N_LIVE]) <= 0) break;
         __builtin_amdgcn_s_sleep(8);
+        clock_role(4);
         if (++idle_spins > (1u << 24)) {
             if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
             break;
@@ -541,7 +605,11 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
         if (n_light) atomicAdd(&P.counters[1], (unsigned long long)n_light);
         if (n_slow) atomicAdd(&P.counters[13], (unsigned long long)n_slow);
     }
-    if (COUNT && P.counters) { atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris); }
+    if (COUNT && P.counters) {
+        atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris);
+        if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&P.counters[16 + i], t_role[i]);
+    }
+    if (P.debug && lane == 0) atomicMax(&P.debug[3 * blockIdx.x + 1], __builtin_amdgcn_s_memrealtime());
 }
 
 } // namespace dev

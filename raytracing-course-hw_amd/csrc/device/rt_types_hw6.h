@@ -29,6 +29,7 @@ struct SceneView6 {
     const GpuNode *fast_light_nodes; // own SAH tree over the same lights: finds the hit lights quickly (order-free for <= 2 hits)
     const Tri6 *fast_lights;         // the light records in that tree's leaf order (ref_index = position in the reference's light order)
     const uint32_t *light_ref;       // the reference light tree without boxes: 4 words {left, right, first, last} per node (left = 0: leaf)
+    const uint16_t *light_sep;       // range-minimum table of the separation depths of neighbouring lights in the reference light tree (scene_prep.h)
     const GpuMaterial6 *materials;
     uint32_t n_tris, n_lights, n_components;
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];

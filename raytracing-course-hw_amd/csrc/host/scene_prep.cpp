@@ -257,6 +257,39 @@ TriIsect make_isect(const float *p /* data, data2, data3 */) {
 
 } // namespace
 
+// Separation depths of neighbouring lights in a reference light tree + sparse table for range minima (see scene_prep.h).
+static void build_light_sep(const std::vector<RefNode> &rn, uint32_t nl, std::vector<uint16_t> &table, uint32_t &table_levels) {
+    std::vector<uint16_t> sep(nl ? nl : 1, 0);
+    if (nl > 1) {
+        std::vector<std::pair<uint32_t, uint32_t>> todo; // node, depth
+        todo.push_back({0u, 0u});
+        while (!todo.empty()) {
+            auto [node, depth] = todo.back();
+            todo.pop_back();
+            const RefNode &nd = rn[node];
+            if (nd.left == 0) { // leaf: its lights are added left to right, so the LAST boundary is the shallowest
+                for (uint32_t b = nd.first; b + 1 < nd.last; b++) sep[b] = (uint16_t)std::min<uint32_t>(65535u, 32768u + (nd.last - 2 - b));
+                continue;
+            }
+            sep[rn[nd.right].first - 1] = (uint16_t)depth; // boundary between the last light of the left child and the first of the right
+            todo.push_back({nd.left, depth + 1});
+            todo.push_back({nd.right, depth + 1});
+        }
+    }
+    uint32_t levels = 1;
+    while ((1u << levels) < (nl ? nl : 1)) levels++;
+    table_levels = levels;
+    table.assign((size_t)levels * (nl ? nl : 1), 0);
+    const size_t stride = nl ? nl : 1;
+    for (size_t b = 0; b < stride; b++) table[b] = sep[b];
+    for (uint32_t j = 1; j < levels; j++)
+        for (size_t b = 0; b < stride; b++) {
+            size_t o2 = b + (1u << (j - 1));
+            uint16_t a = table[(j - 1) * stride + b], c = o2 < stride ? table[(j - 1) * stride + o2] : a;
+            table[j * stride + b] = a < c ? a : c;
+        }
+}
+
 void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     const uint32_t n = d.n_triangles;
     if (n >= 0x7FFFFFFFu) throw std::runtime_error("too many triangles (limit 2^31-2)");
@@ -299,39 +332,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     out.light_bvh_depth = light_builder.depth;
     encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
     encode_ref_tree(light_builder.nodes, out.ref_light_nodes);
-    { // separation depths of neighbouring lights + sparse table for range minima (see scene_prep.h)
-        const std::vector<RefNode> &rn = light_builder.nodes;
-        const uint32_t nl = n_lights;
-        std::vector<uint16_t> sep(nl ? nl : 1, 0);
-        if (nl > 1) {
-            std::vector<std::pair<uint32_t, uint32_t>> todo; // node, depth
-            todo.push_back({0u, 0u});
-            while (!todo.empty()) {
-                auto [node, depth] = todo.back();
-                todo.pop_back();
-                const RefNode &nd = rn[node];
-                if (nd.left == 0) { // leaf: its lights are added left to right, so the LAST boundary is the shallowest
-                    for (uint32_t b = nd.first; b + 1 < nd.last; b++) sep[b] = (uint16_t)std::min<uint32_t>(65535u, 32768u + (nd.last - 2 - b));
-                    continue;
-                }
-                sep[rn[nd.right].first - 1] = (uint16_t)depth; // boundary between the last light of the left child and the first of the right
-                todo.push_back({nd.left, depth + 1});
-                todo.push_back({nd.right, depth + 1});
-            }
-        }
-        uint32_t levels = 1;
-        while ((1u << levels) < (nl ? nl : 1)) levels++;
-        out.light_sep_levels = levels;
-        out.light_sep.assign((size_t)levels * (nl ? nl : 1), 0);
-        const size_t stride = nl ? nl : 1;
-        for (size_t b = 0; b < stride; b++) out.light_sep[b] = sep[b];
-        for (uint32_t j = 1; j < levels; j++)
-            for (size_t b = 0; b < stride; b++) {
-                size_t o2 = b + (1u << (j - 1));
-                uint16_t a = out.light_sep[(j - 1) * stride + b], c = o2 < stride ? out.light_sep[(j - 1) * stride + o2] : a;
-                out.light_sep[j * stride + b] = a < c ? a : c;
-            }
-    }
+    build_light_sep(light_builder.nodes, n_lights, out.light_sep, out.light_sep_levels);
     out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
 
     // ---- 3. records ---------------------------------------------------------------------------------
@@ -507,6 +508,7 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out) {
         std::vector<uint32_t> light_pos(n, 0);
         for (uint32_t i = 0; i < n_lights; i++) light_pos[out.light_order[i]] = i;
         for (uint32_t i = 0; i < n_lights; i++) { out.fast_lights[i] = make(forder[i]); out.fast_lights[i].ref_index = light_pos[forder[i]]; }
+        build_light_sep(light_builder.nodes, n_lights, out.light_sep, out.light_sep_levels);
         for (const RefNode &rn : light_builder.nodes) { out.light_ref.push_back(rn.left); out.light_ref.push_back(rn.right); out.light_ref.push_back(rn.first); out.light_ref.push_back(rn.last); }
         if (out.light_ref.empty()) out.light_ref.assign(4, 0);
         for (uint32_t i : fast_leaf_last) out.fast_lights[i].last = 1;

@@ -43,6 +43,8 @@ struct PreparedScene6 {
     std::vector<Tri6> tris, lights, fast_lights;
     uint32_t fast_light_bvh_depth = 0;
     std::vector<uint32_t> light_ref; // 4 words per reference light-tree node: left, right, first, last
+    std::vector<uint16_t> light_sep; // as PreparedScene::light_sep, over the reference light tree of hw6
+    uint32_t light_sep_levels = 0;
     std::vector<GpuMaterial6> materials;
     std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index
     uint32_t bvh_depth = 0, light_bvh_depth = 0, ref_bvh_depth = 0;

@@ -247,6 +247,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             V.fast_light_nodes = keep(upload(P6.fast_light_nodes, bytes));
             V.fast_lights = keep(upload(P6.fast_lights, bytes));
             V.light_ref = keep(upload(P6.light_ref, bytes));
+            V.light_sep = keep(upload(P6.light_sep, bytes));
             V.materials = keep(upload(P6.materials, bytes));
             V.n_tris = desc->n_triangles;
             V.n_lights = (uint32_t)P6.lights.size();
@@ -718,6 +719,10 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
     P.cost_t = 1; P.cost_l = 1;
     P.counters = scene->d_counters;
     P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
+    if (getenv("RTAMD_DEBUG_COUNTERS")) {
+        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)1024 * 3 * sizeof(unsigned long long)));
+        if (n_blocks_max <= 1024) P.debug = scene->d_pt_debug;
+    }
     const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
     const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
     const uint32_t phases = two_phase ? 2u : 1u;
@@ -740,6 +745,7 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
             if (ph == 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
+            if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
             else hipLaunchKernelGGL(dev::p6_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
@@ -929,9 +935,24 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipMemcpyAsync(h_cnt, scene->d_counters, 512, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         use_persistent = use_persistent && use_wavefront && blocks;
-        if (use_persistent6 && getenv("RTAMD_DEBUG_COUNTERS"))
+        if (use_persistent6 && getenv("RTAMD_DEBUG_COUNTERS")) {
             fprintf(stderr, "[rtamd] persistent hw6 pipeline: %u launches; re-deal %.2f ms on the host (slowest workgroup / mean under the round-robin deal: %.3f); light sums through the slow role %llu of %llu\n",
                     scene->pt_launches, scene->pt_rebalance_ms, scene->pt_imbalance, h_cnt[13], h_cnt[1]);
+            if (count) {
+                const double tt = (double)(h_cnt[16] + h_cnt[17] + h_cnt[18] + h_cnt[19] + h_cnt[20]);
+                fprintf(stderr, "[rtamd] persistent hw6 kernel, wave time by role: closest-hit walks %.1f %%, light walks %.1f %%, shading %.1f %%, slow light sums %.1f %%, idle %.1f %%\n",
+                        100 * h_cnt[16] / tt, 100 * h_cnt[17] / tt, 100 * h_cnt[18] / tt, 100 * h_cnt[19] / tt, 100 * h_cnt[20] / tt);
+            }
+            if (scene->d_pt_debug && scene->pt_blocks <= 1024) {
+                std::vector<unsigned long long> dbg((size_t)scene->pt_blocks * 3);
+                HIP_CHECK(hipMemcpy(dbg.data(), scene->d_pt_debug, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, tmin = ~0ull, tmax = 0; double tsum = 0;
+                for (uint32_t b = 0; b < scene->pt_blocks; b++) if (dbg[3 * b] && dbg[3 * b] < t0) t0 = dbg[3 * b];
+                for (uint32_t b = 0; b < scene->pt_blocks; b++) { unsigned long long e = dbg[3 * b + 1] - t0; tmin = e < tmin ? e : tmin; tmax = e > tmax ? e : tmax; tsum += (double)e; }
+                fprintf(stderr, "[rtamd] persistent hw6 kernel (last launch): %u workgroups, exit times min / mean / max = %.3f / %.3f / %.3f ms after the first start\n",
+                        scene->pt_blocks, tmin * 1e-5, tsum / scene->pt_blocks * 1e-5, tmax * 1e-5);
+            }
+        }
         if (use_persistent6 && h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent hw6 kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");
         scene->pipeline = (use_persistent || use_persistent6) ? RT_PIPELINE_PERSISTENT : (use_wavefront && blocks ? RT_PIPELINE_ROUNDS : RT_PIPELINE_SINGLE);
         if (use_persistent) {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 4
+#define RTAMD_ABI_VERSION 5
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -141,7 +141,20 @@ typedef struct rt_scene_desc {
     uint32_t n_lights;               /* HW2 only */
     const rt_light *lights;
     float ambient_light[3];          /* HW2 only (AMBIENT_LIGHT) */
+    uint32_t build_flags;            /* RT_BUILD_* */
+    uint32_t reserved;
 } rt_scene_desc;
+
+/* rt_scene_desc.build_flags (glTF scenes with per-vertex normals, i.e. the hw7 / hw8 integrators):
+ * RT_BUILD_DEVICE_BVH  build the scene tree on the GPU (binned SAH, device/rt_bvh_build.h: milliseconds instead of the host's replay of
+ *                      the reference's builder, hw8/src/include/bvh.h:34-109) and take the LOAD order as the figure order.  Closest hits
+ *                      are the same triangles; what changes is everything the reference's figure order decides: which of two hits at
+ *                      exactly equal distance wins, the numbering of the emissive triangles (int(u * N) picks a different light for the
+ *                      same random number) and the order of the light-pdf additions.  Frames of such a scene follow the reference's
+ *                      estimator, not its pixels -- the contract of throughput mode (rt_render_params.sample_streams).
+ *                      hw6 scenes (no normals) always get their tree this way: hw6's own tree never was the reference's, the figure
+ *                      order is still replayed on the host and the pixels are the reference's (RTAMD_HOST_BVH=1: host-built tree). */
+#define RT_BUILD_DEVICE_BVH 1u
 
 #define RT_FLAG_OUT_DEVICE 1u /* out_rgb_linear / out_rgb8 are device pointers on the scene's GPU */
 #define RT_FLAG_COUNTERS   2u /* also fill the work counters of rt_stats (slower kernel variant) */
@@ -241,7 +254,10 @@ typedef struct rt_scene_info {
     uint32_t n_triangles, n_lights, n_bvh_nodes, n_light_bvh_nodes;
     uint32_t bvh_depth, light_bvh_depth;
     uint64_t device_bytes;
-    double prep_ms, upload_ms;
+    double prep_ms, upload_ms;   /* host preparation; upload (+ the tree build on the GPU when bvh_on_device) */
+    double bvh_build_ms;         /* GPU time of the on-device scene-tree build (device/rt_bvh_build.h), 0 when built on the host */
+    uint32_t bvh_on_device;      /* 1 = the traversal tree of the scene was built on the GPU */
+    uint32_t reserved;
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);
 /* Light order chosen by preparation (indices into the LOAD-order triangle arrays);

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "librtamd.so")  # 
 RT_INTEGRATOR_HW1, RT_INTEGRATOR_HW2, RT_INTEGRATOR_HW3, RT_INTEGRATOR_HW4, RT_INTEGRATOR_HW5 = 1, 2, 3, 4, 5
 RT_INTEGRATOR_HW6, RT_INTEGRATOR_HW7, RT_INTEGRATOR_HW8 = 6, 7, 8
 RT_FLAG_OUT_DEVICE, RT_FLAG_COUNTERS, RT_FLAG_SAMPLE_SEEDS, RT_FLAG_RUSSIAN_ROULETTE = 1, 2, 4, 8
+RT_BUILD_DEVICE_BVH = 1
 RT_PIPELINE_SINGLE, RT_PIPELINE_ROUNDS, RT_PIPELINE_PERSISTENT = 0, 1, 2
 RT_OK = 0
 RT_ERR_NO_DEVICE = -2
@@ -67,7 +68,8 @@ class rt_scene_desc(C.Structure):
                 ("environment_map", C.POINTER(rt_image)),
                 ("n_primitives", C.c_uint32), ("primitives", C.POINTER(rt_primitive)),
                 ("camera", rt_camera), ("bg_color", C.c_float * 3),
-                ("n_lights", C.c_uint32), ("lights", C.POINTER(rt_light)), ("ambient_light", C.c_float * 3)]
+                ("n_lights", C.c_uint32), ("lights", C.POINTER(rt_light)), ("ambient_light", C.c_float * 3),
+                ("build_flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class rt_render_params(C.Structure):
@@ -88,7 +90,8 @@ class rt_stats(C.Structure):
 class rt_scene_info(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_lights", C.c_uint32), ("n_bvh_nodes", C.c_uint32),
                 ("n_light_bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("light_bvh_depth", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("prep_ms", C.c_double), ("upload_ms", C.c_double)]
+                ("device_bytes", C.c_uint64), ("prep_ms", C.c_double), ("upload_ms", C.c_double),
+                ("bvh_build_ms", C.c_double), ("bvh_on_device", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # Every symbol include/rtamd.h declares; tests/test_abi.py checks the library exports them all.
@@ -326,10 +329,12 @@ class MultiScene:
 class Scene:
     """A prepared scene resident in HBM on the current HIP device (rt_scene)."""
 
-    def __init__(self, data):
+    def __init__(self, data, build_flags=0):
         self.data = data
         self._h = C.c_void_p()
-        _check(lib.rt_scene_create(C.byref(data.desc), C.byref(self._h)))
+        desc = rt_scene_desc.from_buffer_copy(data.desc)   # the arrays stay owned by `data`
+        desc.build_flags = build_flags
+        _check(lib.rt_scene_create(C.byref(desc), C.byref(self._h)))
 
     def close(self):
         if self._h:

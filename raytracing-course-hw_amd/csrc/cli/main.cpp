@@ -46,6 +46,11 @@ int main(int argc, const char *argv[]) {
         fprintf(stderr, "usage: %s <scene.gltf> <width> <height> <samples> <out.ppm> [<envmap.png>]\n       %s <scene.txt> <out.ppm>\n", argv[0], argv[0]);
         return 2;
     }
+    rt_scene_desc desc = *rt_host_scene_desc(hs);
+    // RTAMD_FAST_BUILD=1: scene tree built on the GPU, frames follow the reference's estimator instead of its pixels (rtamd.h);
+    // RTAMD_STREAMS=k: throughput mode with k random streams per pixel
+    if (getenv("RTAMD_FAST_BUILD") && desc.normals) desc.build_flags |= RT_BUILD_DEVICE_BVH;
+    if (const char *e = getenv("RTAMD_STREAMS")) { int v = atoi(e); if (v > 1) p.sample_streams = v; }
     std::vector<uint8_t> rgb8(rt_output_elems(&p));
     if (rgb8.empty()) { fprintf(stderr, "error: bad image size %dx%d\n", p.width, p.height); return 1; }
     rt_stats st;
@@ -53,13 +58,13 @@ int main(int argc, const char *argv[]) {
     if (const char *e = getenv("RTAMD_DEVICES")) { int v = atoi(e); if (v >= 1 && v < n_dev) n_dev = v; }
     if (n_dev > 1 && p.integrator != RT_INTEGRATOR_HW1) {
         rt_multi *multi = nullptr;
-        if (rt_multi_create(rt_host_scene_desc(hs), nullptr, n_dev, &multi) != RT_OK) return die();
+        if (rt_multi_create(&desc, nullptr, n_dev, &multi) != RT_OK) return die();
         if (rt_multi_render(multi, &p, nullptr, rgb8.data(), &st) != RT_OK) return die();
         fprintf(stderr, "render: %d GPUs, slowest %.3f ms, %.2f Msamples/s over the whole call\n", n_dev, st.kernel_ms, st.samples / (st.total_ms * 1e3));
         rt_multi_destroy(multi);
     } else {
         rt_scene *scene = nullptr;
-        if (rt_scene_create(rt_host_scene_desc(hs), &scene) != RT_OK) return die();
+        if (rt_scene_create(&desc, &scene) != RT_OK) return die();
         if (rt_render(scene, &p, nullptr, rgb8.data(), &st) != RT_OK) return die();
         fprintf(stderr, "render: %.3f ms on the GPU, %.2f Msamples/s\n", st.kernel_ms, st.samples / (st.kernel_ms * 1e3));
         rt_scene_destroy(scene);

@@ -1,0 +1,25 @@
+// Host side of the on-device scene-tree builder (device/rt_bvh_build.h, rtamd_build.hip).
+#pragma once
+#include "../device/rt_types.h"
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace rtamd {
+
+struct DeviceTree {
+    GpuNode *nodes = nullptr;   // hipMalloc'ed, n_nodes two-box nodes, numbered level by level
+    uint32_t *order = nullptr;  // hipMalloc'ed, n entries: leaf slot -> primitive (load index)
+    uint8_t *last = nullptr;    // hipMalloc'ed, n entries: 1 = last slot of its leaf
+    uint32_t n_nodes = 0, depth = 0;
+    float build_ms = 0.f;       // GPU time of the build (HIP events)
+};
+
+// d_boxes: 8 floats per primitive (lo.xyz, -, hi.xyz, -) on the current device; n >= 1.  Synchronous.  Throws HipError.
+DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n);
+void free_device_tree(DeviceTree &t);
+
+// out[i] = in[order[i]] for records of elem_bytes (a multiple of 16); then the 32-bit word at mark_word_offset of every record whose
+// slot is the last of its leaf is set to 1 (mark_word_offset < 0: no marks).
+void gather_records(const void *d_in, void *d_out, const DeviceTree &t, uint32_t n, uint32_t elem_bytes, int mark_word_offset);
+
+} // namespace rtamd

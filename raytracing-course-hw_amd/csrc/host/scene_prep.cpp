@@ -290,7 +290,7 @@ static void build_light_sep(const std::vector<RefNode> &rn, uint32_t nl, std::ve
         }
 }
 
-void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
+void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_device) {
     const uint32_t n = d.n_triangles;
     if (n >= 0x7FFFFFFFu) throw std::runtime_error("too many triangles (limit 2^31-2)");
     if (n && (!d.positions || !d.material_index)) throw std::runtime_error("scene has triangles but no positions/material_index");
@@ -311,14 +311,21 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
     }
     out.figure_order.resize(n);
     for (uint32_t i = 0; i < n; i++) out.figure_order[i] = i;
-    RefBuilder scene_builder(keys, boxes, out.figure_order);
-    scene_builder.run(n);
-    out.bvh_depth = scene_builder.depth;
-    out.n_ref_nodes = (uint32_t)scene_builder.nodes.size();
     std::vector<uint32_t> scene_leaf_last, light_leaf_last;
-    encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
-    bfs_top_first(out.nodes, 512);
-    encode_ref_tree(scene_builder.nodes, out.ref_nodes);
+    if (tree_on_device) {
+        // RT_BUILD_DEVICE_BVH: no replay of the reference's builder -- the figure order is the LOAD order, the records below stay in
+        // it (tri_box doubles as the builder's input) and rtamd_build.hip makes the tree and the leaf order on the GPU
+        out.nodes.clear();
+        encode_ref_tree(std::vector<RefNode>(), out.ref_nodes);
+    } else {
+        RefBuilder scene_builder(keys, boxes, out.figure_order);
+        scene_builder.run(n);
+        out.bvh_depth = scene_builder.depth;
+        out.n_ref_nodes = (uint32_t)scene_builder.nodes.size();
+        encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
+        bfs_top_first(out.nodes, 512);
+        encode_ref_tree(scene_builder.nodes, out.ref_nodes);
+    }
 
     // ---- 2. light order ---------------------------------------------------------------------------
     auto emissive = [&](uint32_t tri) { // distributions.h:104-109: the FACTOR decides, not the texture
@@ -427,7 +434,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out) {
 }
 
 
-void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out) {
+void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on_device) {
     const uint32_t n = d.n_triangles;
     if (n >= 0x7FFFFFFFu) throw std::runtime_error("too many triangles (limit 2^31-2)");
     if (n && (!d.positions || !d.material_index)) throw std::runtime_error("scene has triangles but no positions/material_index");
@@ -468,13 +475,20 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out) {
     std::vector<uint32_t> light_leaf_last, scene_leaf_last;
     encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
     out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
-    // 3. own scene tree: the same full-sweep SAH builder keyed on the data3 vertex (as hw8 does)
+    // 3. own scene tree: the same full-sweep SAH builder keyed on the data3 vertex (as hw8 does) -- or, when the caller builds the
+    //    tree on the GPU (device/rt_bvh_build.h), the records stay in LOAD order and the boxes go along
     std::vector<uint32_t> my_order(n);
     for (uint32_t i = 0; i < n; i++) my_order[i] = i;
-    RefBuilder mine(keys, boxes, my_order);
-    mine.run(n);
-    out.bvh_depth = mine.depth;
-    encode_tree(mine.nodes, out.nodes, scene_leaf_last);
+    if (tree_on_device) {
+        out.boxes8.assign((size_t)n * 8, 0.f);
+        for (uint32_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) { out.boxes8[8 * (size_t)i + k] = boxes[i].lo[k]; out.boxes8[8 * (size_t)i + 4 + k] = boxes[i].hi[k]; }
+    } else {
+        RefBuilder mine(keys, boxes, my_order);
+        mine.run(n);
+        out.bvh_depth = mine.depth;
+        encode_tree(mine.nodes, out.nodes, scene_leaf_last);
+    }
     auto make = [&](uint32_t src) {
         const float *p = d.positions + 9 * (size_t)src;
         Tri6 t;

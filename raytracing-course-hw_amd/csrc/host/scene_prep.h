@@ -35,7 +35,9 @@ struct PreparedScene {
 };
 
 // Throws std::runtime_error on invalid input.
-void prepare_scene(const rt_scene_desc &desc, PreparedScene &out);
+// tree_on_device (rt_scene_desc.build_flags & RT_BUILD_DEVICE_BVH): the reference's scene-tree build is not replayed; figure order =
+// LOAD order, `nodes` stays empty, `isect` / `shade` / `tri_box` stay in LOAD order without leaf marks, for device/rt_bvh_build.h.
+void prepare_scene(const rt_scene_desc &desc, PreparedScene &out, bool tree_on_device = false);
 
 // hw6 flavour (flat-shaded triangles, hw6/src/scene.cpp): own scene tree + reference-topology light tree.
 struct PreparedScene6 {
@@ -44,12 +46,15 @@ struct PreparedScene6 {
     uint32_t fast_light_bvh_depth = 0;
     std::vector<uint32_t> light_ref; // 4 words per reference light-tree node: left, right, first, last
     std::vector<uint16_t> light_sep; // as PreparedScene::light_sep, over the reference light tree of hw6
+    std::vector<float> boxes8;       // tree_on_device only
     uint32_t light_sep_levels = 0;
     std::vector<GpuMaterial6> materials;
     std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index
     uint32_t bvh_depth = 0, light_bvh_depth = 0, ref_bvh_depth = 0;
 };
-void prepare_scene_hw6(const rt_scene_desc &desc, PreparedScene6 &out);
+// tree_on_device: skip the own scene tree; `tris` stay in LOAD order (ref_index set, no leaf marks) and `boxes8` (lo.xyz, -, hi.xyz, -
+// per triangle) is filled for device/rt_bvh_build.h.
+void prepare_scene_hw6(const rt_scene_desc &desc, PreparedScene6 &out, bool tree_on_device = false);
 
 // hw5 flavour (.txt scene with TRIANGLE figures): the reference's figure order, BVH and light list / light BVH
 // (hw5/src/scene.cpp:8-23, hw5/src/include/distributions.h:180-198), both trees in the reference's topology.

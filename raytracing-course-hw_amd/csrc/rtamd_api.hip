@@ -15,6 +15,8 @@
 #include "host/host_scene.h"
 #include "host/png.h"
 #include "host/scene_prep.h"
+#include "host/hip_check.h"
+#include "host/device_build.h"
 #include "device/rt_kernels_hw8.h"
 #include "device/rt_wavefront.h"
 #include "device/rt_persistent.h"
@@ -33,15 +35,6 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 using namespace rtamd;
 
 namespace {
-
-struct HipError : std::runtime_error {
-    explicit HipError(const std::string &m) : std::runtime_error(m) {}
-};
-#define HIP_CHECK(expr)                                                                                   \
-    do {                                                                                                  \
-        hipError_t e_ = (expr);                                                                           \
-        if (e_ != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_));          \
-    } while (0)
 
 template <class T> T *upload(const std::vector<T> &v, uint64_t &bytes) {
     if (v.empty()) { // keep pointers valid: one dummy element
@@ -103,6 +96,7 @@ struct rt_scene {
     float *d_partial = nullptr;      // throughput mode: per-stream pixel sums
     size_t partial_bytes = 0;
     std::vector<hipEvent_t> ev_pool; // brackets every launch of the dominant kernel when stats are requested
+    bool device_tree = false;                 // RT_BUILD_DEVICE_BVH: figure order = LOAD order, no reference trees
     unsigned long long *d_pt_debug = nullptr; // persistent pipeline: per workgroup {start, exit time, paths} (RTAMD_DEBUG_COUNTERS)
     float4 *pt_r0 = nullptr;         // persistent pipeline: path records of one pass
     uint32_t *pt_groups = nullptr;   // [cost per group | group_ofs (n_blocks + 1) | group_ids]: the re-deal between the phases of a frame
@@ -230,18 +224,47 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         }
         // A scene without per-vertex normals can only be an hw6 scene (flat shading, hw6/src/sceneio.cpp:186-225).
         if (desc->n_triangles && !desc->normals) {
+            // hw6's scene tree is the library's own (the reference's is degenerate, rt_kernels_hw6.h), so it can be built on the GPU
+            // without touching the replay: the tie rule reads the reference's figure index from the record.
+            const bool tree_on_device = desc->n_triangles >= 64 && !getenv("RTAMD_HOST_BVH");
             PreparedScene6 P6;
-            prepare_scene_hw6(*desc, P6);
+            prepare_scene_hw6(*desc, P6, tree_on_device);
             double t1 = now_ms();
+            uint64_t bytes = 0;
+            SceneView6 &V = s->view6;
+            auto keep = [&](auto *p) { s->allocations.push_back((void *)p); return p; };
+            if (tree_on_device) {
+                uint64_t scratch = 0;
+                Tri6 *d_load = upload(P6.tris, bytes);
+                float *d_boxes = upload(P6.boxes8, scratch);
+                DeviceTree t;
+                Tri6 *d_tris = nullptr;
+                try {
+                    t = build_tree_on_device(d_boxes, desc->n_triangles);
+                    HIP_CHECK(hipMalloc((void **)&d_tris, (size_t)desc->n_triangles * sizeof(Tri6)));
+                    gather_records(d_load, d_tris, t, desc->n_triangles, sizeof(Tri6), 13); // word 13 = Tri6::last
+                    HIP_CHECK(hipDeviceSynchronize());
+                } catch (...) {
+                    (void)hipFree(d_load); (void)hipFree(d_boxes); if (d_tris) (void)hipFree(d_tris);
+                    free_device_tree(t);
+                    throw;
+                }
+                (void)hipFree(d_load); (void)hipFree(d_boxes);
+                (void)hipFree(t.order); (void)hipFree(t.last); t.order = nullptr; t.last = nullptr;
+                V.nodes = keep(t.nodes);
+                V.tris = keep(d_tris);
+                bytes += (uint64_t)t.n_nodes * sizeof(GpuNode);
+                P6.bvh_depth = t.depth;
+                P6.nodes.resize(t.n_nodes); // node count for rt_scene_info
+                s->info.bvh_build_ms = t.build_ms; s->info.bvh_on_device = 1;
+            } else {
+                V.nodes = keep(upload(P6.nodes, bytes));
+                V.tris = keep(upload(P6.tris, bytes));
+            }
             if (P6.bvh_depth > RT6_STACK_SIZE - 2 || P6.light_bvh_depth > RT6_STACK_SIZE - 2 || P6.fast_light_bvh_depth > RT6_STACK_SIZE - 2)
                 return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P6.bvh_depth) + "/" +
                                               std::to_string(P6.light_bvh_depth) + ")");
             s->hw6_lds_stack = P6.bvh_depth <= RT6_LDS_STACK && P6.fast_light_bvh_depth <= RT6_LDS_STACK; // both own trees fit the LDS stack columns
-            uint64_t bytes = 0;
-            SceneView6 &V = s->view6;
-            auto keep = [&](auto *p) { s->allocations.push_back((void *)p); return p; };
-            V.nodes = keep(upload(P6.nodes, bytes));
-            V.tris = keep(upload(P6.tris, bytes));
             V.light_nodes = keep(upload(P6.light_nodes, bytes));
             V.lights = keep(upload(P6.lights, bytes));
             V.fast_light_nodes = keep(upload(P6.fast_light_nodes, bytes));
@@ -276,25 +299,58 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             *out = s.release();
             return RT_OK;
         }
+        if (desc->build_flags & ~RT_BUILD_DEVICE_BVH) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: unknown build_flags");
+        const bool tree_on_device = (desc->build_flags & RT_BUILD_DEVICE_BVH) && desc->n_triangles >= 64; // a handful of triangles: the host builder (same contract: it then runs on the LOAD order's keys)
         PreparedScene P;
-        prepare_scene(*desc, P);
+        prepare_scene(*desc, P, tree_on_device);
         double t1 = now_ms();
-        if (P.bvh_depth > RT_STACK_SIZE - 2 || P.light_bvh_depth > RT_STACK_SIZE - 2)
-            return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P.bvh_depth) + "/" +
-                                          std::to_string(P.light_bvh_depth) + ")");
         uint64_t bytes = 0;
         SceneView &V = s->view;
         auto keep = [&](auto *p) { s->allocations.push_back((void *)p); return p; };
-        V.nodes = keep(upload(P.nodes, bytes));
-        V.tri_isect = keep(upload(P.isect, bytes));
-        V.tri_shade = keep(upload(P.shade, bytes));
+        if (tree_on_device) {
+            const uint32_t n = desc->n_triangles;
+            TriIsect *d_isect = upload(P.isect, bytes), *o_isect = nullptr;
+            TriShade *d_shade = upload(P.shade, bytes), *o_shade = nullptr;
+            float *d_box = upload(P.tri_box, bytes), *o_box = nullptr;
+            DeviceTree t;
+            try {
+                t = build_tree_on_device(d_box, n);
+                HIP_CHECK(hipMalloc((void **)&o_isect, (size_t)n * sizeof(TriIsect)));
+                HIP_CHECK(hipMalloc((void **)&o_shade, (size_t)n * sizeof(TriShade)));
+                HIP_CHECK(hipMalloc((void **)&o_box, (size_t)n * 32));
+                gather_records(d_isect, o_isect, t, n, sizeof(TriIsect), 11); // word 11 = TriIsect::pad, the leaf mark
+                gather_records(d_shade, o_shade, t, n, sizeof(TriShade), -1);
+                gather_records(d_box, o_box, t, n, 32, -1);
+                HIP_CHECK(hipDeviceSynchronize());
+            } catch (...) {
+                (void)hipFree(d_isect); (void)hipFree(d_shade); (void)hipFree(d_box);
+                if (o_isect) (void)hipFree(o_isect); if (o_shade) (void)hipFree(o_shade); if (o_box) (void)hipFree(o_box);
+                free_device_tree(t);
+                throw;
+            }
+            (void)hipFree(d_isect); (void)hipFree(d_shade); (void)hipFree(d_box);
+            (void)hipFree(t.order); (void)hipFree(t.last); t.order = nullptr; t.last = nullptr;
+            V.nodes = keep(t.nodes); V.tri_isect = keep(o_isect); V.tri_shade = keep(o_shade); V.tri_box = keep(o_box);
+            bytes += (uint64_t)t.n_nodes * sizeof(GpuNode);
+            P.bvh_depth = t.depth;
+            P.nodes.resize(t.n_nodes);
+            s->info.bvh_build_ms = t.build_ms; s->info.bvh_on_device = 1;
+            s->device_tree = true;
+        } else {
+            V.nodes = keep(upload(P.nodes, bytes));
+            V.tri_isect = keep(upload(P.isect, bytes));
+            V.tri_shade = keep(upload(P.shade, bytes));
+            V.tri_box = keep(upload(P.tri_box, bytes));
+        }
+        if (P.bvh_depth > RT_STACK_SIZE - 2 || P.light_bvh_depth > RT_STACK_SIZE - 2)
+            return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P.bvh_depth) + "/" +
+                                          std::to_string(P.light_bvh_depth) + ")");
         V.light_nodes = keep(upload(P.light_nodes, bytes));
         V.light_sep = keep(upload(P.light_sep, bytes));
         V.ref_nodes = keep(upload(P.ref_nodes, bytes));
         V.ref_light_nodes = keep(upload(P.ref_light_nodes, bytes));
-        V.tri_box = keep(upload(P.tri_box, bytes));
         V.box_c2 = P.box_c2;
-        V.exact_boxes = getenv("RTAMD_NO_EXACT_BOXES") ? 0u : 1u;
+        V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || tree_on_device) ? 0u : 1u; // no reference tree to be exact about in a device-built scene
         V.lights = keep(upload(P.lights, bytes));
         V.materials = keep(upload(P.materials, bytes));
         V.images = keep(upload(P.images, bytes));

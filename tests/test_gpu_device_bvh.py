@@ -1,0 +1,89 @@
+"""Scene tree built on the GPU (device/rt_bvh_build.h; the reference builds on the host: hw8/src/include/bvh.h:34-109).
+
+hw6: the library's own tree never was the reference's, so the device-built tree is the default and must leave the replay untouched —
+frames bit-identical to the host-built tree's (and, in test_gpu_parity_hw6.py, to the oracle and to the reference's own floats).
+hw8 (rt_scene_desc.build_flags = RT_BUILD_DEVICE_BVH): the figure order becomes the LOAD order, so only what does not depend on the
+reference's figure order can be compared exactly: closest hits.  A scene without emissive triangles and without ties is such a case
+(every pixel is a function of closest hits and the random stream); scenes with lights are compared statistically."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import pin_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _tieless_soup(rt, n=1500, seed=11):
+    """pin_cases.random_triangle_scene without its exact duplicates and without emissive materials, against a bright background."""
+    sd = pin_cases.random_triangle_scene(n=n, seed=seed, n_emissive_mats=0)
+    rng = np.random.default_rng(seed + 1)
+    sd.positions[n // 2: n // 2 + 20] += rng.normal(0, 0.05, (20, 9)).astype(np.float32)
+    sd.bg = (0.6, 0.7, 0.9)
+    sd._build_desc()
+    return sd
+
+
+def test_hw6_device_tree_leaves_the_replay_untouched(rt, monkeypatch):
+    sd = pin_cases.load_hw6("practice6_2")
+    scene = rt.Scene(sd)
+    info = scene.info()
+    assert info.bvh_on_device == 1 and 0 < info.bvh_depth <= 28 and info.bvh_build_ms > 0
+    a, a8, st = scene.render(160, 160, 4, integrator=rt.RT_INTEGRATOR_HW6, counters=True)
+    scene.close()
+    monkeypatch.setenv("RTAMD_HOST_BVH", "1")
+    host = rt.Scene(sd)
+    hinfo = host.info()
+    assert hinfo.bvh_on_device == 0
+    b, b8, hst = host.render(160, 160, 4, integrator=rt.RT_INTEGRATOR_HW6, counters=True)
+    host.close()
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a8, b8)
+    assert st.closest_hit_queries == hst.closest_hit_queries and st.light_pdf_queries == hst.light_pdf_queries
+    print(f"practice6_2: device tree {info.n_bvh_nodes} nodes, depth {info.bvh_depth}, built in {info.bvh_build_ms:.2f} ms on the GPU; "
+          f"node visits per sample {st.node_visits / st.samples:.1f} (host-built tree: {hst.node_visits / hst.samples:.1f}, depth {hinfo.bvh_depth})")
+    assert st.node_visits <= 1.15 * hst.node_visits
+
+
+@pytest.mark.parametrize("n", [64, 1500, 20000])
+def test_hw8_closest_hits_do_not_depend_on_the_tree(rt, monkeypatch, n):
+    sd = _tieless_soup(rt, n=n)
+    w, h, spp = 96, 64, 6
+    dev = rt.Scene(sd, build_flags=rt.RT_BUILD_DEVICE_BVH)
+    info = dev.info()
+    assert info.bvh_on_device == 1 and info.bvh_depth <= 28
+    a, a8, st = dev.render(w, h, spp, counters=True)
+    again, _, _ = rt.Scene(sd, build_flags=rt.RT_BUILD_DEVICE_BVH).render(w, h, spp)
+    assert np.array_equal(a, again, equal_nan=True)                  # the build is deterministic
+    dev.close()
+    monkeypatch.setenv("RTAMD_NO_EXACT_BOXES", "1")                  # the same semantics on the host-built tree: padded boxes decide
+    host = rt.Scene(sd)
+    b, b8, hst = host.render(w, h, spp, counters=True)
+    host.close()
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a8, b8)
+    assert st.closest_hit_queries == hst.closest_hit_queries
+    print(f"soup n={n}: device tree depth {info.bvh_depth}, {st.node_visits / st.samples:.1f} node visits per sample (reference topology: {hst.node_visits / hst.samples:.1f})")
+    # and against the oracle (reference tree, reference box tests): identical up to the box-rounding class
+    ref, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
+    differing = int(np.any(a != ref, axis=2).sum())
+    print(f"    pixels differing from the oracle: {differing} of {w * h}")
+    assert differing <= 2
+
+
+def test_hw8_scene_with_lights_is_statistically_the_same(rt, sphere_scene):
+    w, h, spp, k = 64, 48, 512, 8
+    a, _, _ = rt.Scene(sphere_scene, build_flags=rt.RT_BUILD_DEVICE_BVH).render(w, h, spp, sample_streams=k)
+    b, _, _ = rt.Scene(sphere_scene).render(w, h, spp, sample_streams=k)
+    assert not np.array_equal(a, b)                                  # the light numbering differs, so do the pixels
+    ma, mb = a.astype(np.float64).mean(axis=(0, 1)), b.astype(np.float64).mean(axis=(0, 1))
+    se = b.astype(np.float64).std(axis=(0, 1)) / np.sqrt(w * h)
+    print(f"sphere scene, {spp} spp: mean radiance device tree {ma}, reference order {mb}")
+    assert np.all(np.abs(ma - mb) <= 0.02 * np.abs(mb) + 4 * se)
+    blur = lambda x: x.reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+    assert np.abs(blur(a) - blur(b)).max() <= 0.15 * max(1e-3, blur(b).max())
+
+
+def test_unknown_build_flags_are_refused(rt, sphere_scene):
+    with pytest.raises(Exception):
+        rt.Scene(sphere_scene, build_flags=0x80)

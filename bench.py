@@ -358,6 +358,26 @@ def main():
                           "parallelism": f"pixel tiles {TILE}x{TILE} round-robin over {world} GPU(s)" + ((", gloo gather of u8 tiles (one-GPU rehearsal)" if rehearsal else ", RCCL gather of u8 tiles") if world > 1 else ""),
                           "bvh_nodes": int(info.n_bvh_nodes), "bvh_depth": int(info.bvh_depth), "light_bvh_depth": int(info.light_bvh_depth), "scene_prep_ms": round(info.prep_ms, 1), "scene_upload_ms": round(info.upload_ms, 1),
                           "scene_load_ms": round(t_load * 1e3, 1), "device_bytes": int(info.device_bytes)}
+        if world == 1:
+            # Untimed side measurement: the same scene with its tree built on the GPU (RT_BUILD_DEVICE_BVH).  Not the
+            # headline: the figure order becomes the load order, so these frames follow the reference's estimator, not its pixels.
+            try:
+                t0 = time.perf_counter()
+                fast = rt.Scene(sd, build_flags=rt.RT_BUILD_DEVICE_BVH)
+                create_ms = (time.perf_counter() - t0) * 1e3
+                fi = fast.info()
+                fp = rt.make_params(W, H, min(SPP, 64), tile=TILE, stream=stream.cuda_stream, sample_streams=8)
+                fst = min((fast.render_device(fp, out_rgb.data_ptr(), out_rgb8.data_ptr()) for _ in range(2)), key=lambda t: t.kernel_ms)
+                fcp = rt.make_params(W, H, min(SPP, 4), tile=TILE, flags=rt.RT_FLAG_COUNTERS, stream=stream.cuda_stream)
+                fct = fast.render_device(fcp, out_rgb.data_ptr(), None)
+                fast.close()
+                base["config"]["device_built_tree"] = {"scene_create_ms": round(create_ms, 1), "host_prep_ms": round(fi.prep_ms, 1), "gpu_build_ms": round(fi.bvh_build_ms, 2),
+                                                       "bvh_nodes": int(fi.n_bvh_nodes), "bvh_depth": int(fi.bvh_depth),
+                                                       "node_visits_per_sample": round(fct.node_visits / max(1, fct.samples), 2),
+                                                       "msamples_per_s_throughput_mode_k8": round(fst.samples / fst.kernel_ms / 1e3, 1),
+                                                       "note": "untimed side measurement; frames of such a scene are statistically, not pixel-wise, the reference's"}
+            except Exception as e:  # the side measurement must not take the bench line down
+                base["config"]["device_built_tree"] = {"error": str(e)}
         base["roofline"] = roofline
         base["cpu_baseline"] = cpu
         print(json.dumps(base), flush=True)

@@ -44,6 +44,7 @@ struct Box { V3 mn, mx; };
 
 struct Counters { uint64_t closest = 0, lightq = 0, boxes = 0, tris = 0; };
 static thread_local Counters tl_cnt;
+static thread_local std::vector<float> *tl_trace = nullptr; // diagnostic query log of one pixel (rto_hw8_trace_pixel)
 static bool g_debug_bruteforce = false;
 
 // ---- primitives.cpp ---------------------------------------------------------------------------
@@ -531,7 +532,12 @@ struct Scene {
         if (recLimit == 0) return V3{0., 0., 0.};
         Hit h; int idx = -1;
         tl_cnt.closest++;
-        if (!bvh.intersect(figs, bvh.root, ro, rd, false, 0.f, h, idx)) {
+        const bool found = bvh.intersect(figs, bvh.root, ro, rd, false, 0.f, h, idx);
+        if (tl_trace) { // diagnostic (rto_hw8_trace_pixel): every closest-hit query of the traced pixel
+            const float rec[12] = {ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, found ? h.t : -1.f, found ? (float)idx : -1.f, found && h.inside ? 1.f : 0.f, found ? h.tu : 0.f, found ? h.tv : 0.f, (float)recLimit};
+            tl_trace->insert(tl_trace->end(), rec, rec + 12);
+        }
+        if (!found) {
             if (!has_env) return bg;
             float tx = 0.5 + 0.5 * std::atan2((double)rd.z, (double)rd.x) / M_PI;
             float ty = 0.5 - std::asin((double)rd.y) / M_PI;
@@ -655,6 +661,21 @@ void rto_hw8_bvh_stats(void *p, uint32_t *out4) {
 // the reference loop with the engine seeded y*width + x + k*width*height.  0 = the reference's seeding.
 static uint32_t g_seed_offset = 0;
 void rto_hw8_set_seed_offset(uint32_t off) { g_seed_offset = off; }
+
+// Diagnostic: the closest-hit queries of one pixel's replay, 12 floats each (origin, direction, t or -1, figure index or -1, inside,
+// texture u, v, remaining depth); returns the number of floats written (at most cap).
+int rto_hw8_trace_pixel(void *p, int width, int height, int samples, int ray_depth, int x, int y, float *out, int cap) {
+    Scene *s = (Scene *)p;
+    s->width = width; s->height = height; s->samples = samples; s->rayDepth = ray_depth > 0 ? ray_depth : 6;
+    std::vector<float> log;
+    tl_trace = &log;
+    rng_t rng((uint32_t)(y * width + x) + g_seed_offset);
+    (void)s->get_pixel(rng, x, y);
+    tl_trace = nullptr;
+    int n = (int)log.size() < cap ? (int)log.size() : cap;
+    memcpy(out, log.data(), (size_t)n * sizeof(float));
+    return n;
+}
 
 // Render the pixel rectangle [x0,x0+w) x [y0,y0+h) of a width x height image.
 // out_rgb: w*h*3 linear float radiance (nullable); out8: w*h*3 tonemapped bytes (nullable).

@@ -62,6 +62,7 @@ struct BvbView {
     BvbState *st;
     uint32_t *order;                         // leaf slot -> primitive
     GpuNode *out_nodes;
+    float abs_pad;                           // absolute part of the padding of the emitted boxes (scene_prep.cpp pad_box)
 };
 
 __device__ __forceinline__ uint32_t bvb_ord(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -343,10 +344,10 @@ __global__ void bvb_place_kernel(BvbView B) {
     B.order[N->rank + atomicAdd(&N->clo[0], 1u)] = p;
 }
 
-__device__ __forceinline__ void bvb_pad_box(const float *lo, const float *hi, float *olo, float *ohi) { // scene_prep.cpp pad_box
+__device__ __forceinline__ void bvb_pad_box(const float *lo, const float *hi, float *olo, float *ohi, float abs_pad) { // scene_prep.cpp pad_box
     for (int k = 0; k < 3; k++) {
         const float mag = fmaxf(fabsf(lo[k]), fabsf(hi[k]));
-        const float pad = mag * 7.62939453125e-06f + 1e-30f;
+        const float pad = mag * 7.62939453125e-06f + abs_pad + 1e-30f;
         olo[k] = lo[k] - pad; ohi[k] = hi[k] + pad;
     }
 }
@@ -367,7 +368,7 @@ __global__ void bvb_emit_kernel(BvbView B) {
         }
         if (n_nodes == 1) { // the root is a leaf: wrap it (scene_prep.cpp encode_tree)
             GpuNode g;
-            bvb_pad_box(N->lo, N->hi, g.lo0, g.hi0);
+            bvb_pad_box(N->lo, N->hi, g.lo0, g.hi0, B.abs_pad);
             g.child0 = (int32_t)(0x80000000u | 0u); g.cnt0 = (int32_t)N->count;
             for (int k = 0; k < 3; k++) { g.lo1[k] = 3.0e38f; g.hi1[k] = 3.0e38f; }
             g.child1 = (int32_t)0xFFFFFFFFu; g.cnt1 = 0;
@@ -378,8 +379,8 @@ __global__ void bvb_emit_kernel(BvbView B) {
     }
     const BvbNode *L = B.nodes + N->left, *R = L + 1;
     GpuNode g;
-    bvb_pad_box(L->lo, L->hi, g.lo0, g.hi0);
-    bvb_pad_box(R->lo, R->hi, g.lo1, g.hi1);
+    bvb_pad_box(L->lo, L->hi, g.lo0, g.hi0, B.abs_pad);
+    bvb_pad_box(R->lo, R->hi, g.lo1, g.hi1, B.abs_pad);
     if (L->left == 0) { g.child0 = (int32_t)(0x80000000u | L->rank); g.cnt0 = (int32_t)L->count; } else { g.child0 = (int32_t)L->rank; g.cnt0 = 0; }
     if (R->left == 0) { g.child1 = (int32_t)(0x80000000u | R->rank); g.cnt1 = (int32_t)R->count; } else { g.child1 = (int32_t)R->rank; g.cnt1 = 0; }
     B.out_nodes[N->rank] = g;

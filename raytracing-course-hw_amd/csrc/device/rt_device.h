@@ -160,16 +160,16 @@ RT_DEV bool tri_test(const TriIsect &T, F3 o, F3 d, float &t, float &u, float &v
     return true;
 }
 
-// tri_test for a closest-hit walk that already holds a hit at best_t: a triangle whose plane lies beyond best_t (by more than
-// the walkers' tie tolerance) cannot become the closest hit whatever its barycentrics are, so their two divisions are skipped.
-// Exactly the same accept / reject decisions as tri_test for every triangle that could still matter.
-RT_DEV bool tri_test_closer(const TriIsect &T, F3 o, F3 d, float best_t, float &t, float &u, float &v, bool &inside) {
+// tri_test for a closest-hit walk that already holds a hit: a triangle whose plane lies beyond keep_t (the best t plus the walkers'
+// look-behind, rt_exact.h) can neither become the closest hit nor matter as its runner-up whatever its barycentrics are, so their
+// two divisions are skipped.  Exactly the same accept / reject decisions as tri_test for every triangle that could still matter.
+RT_DEV bool tri_test_closer(const TriIsect &T, F3 o, F3 d, float keep_t, float &t, float &u, float &v, bool &inside) {
     F3 a = f3(T.ax, T.ay, T.az), n = f3(T.nx, T.ny, T.nz);
     F3 ro = o - a;
     float dn = dot(d, n);
     t = -dot(ro, n) / dn;
     if (!(t > 0 && t < RT_T_MAX)) return false;
-    if (t > best_t + 4.8e-7f * t) return false;
+    if (t > keep_t) return false;
     inside = dn > 0;
     F3 p = ro + t * d;
     float c1 = RT_MAGIC1_0 * p.x + RT_MAGIC1_1 * p.y + RT_MAGIC1_2 * p.z;
@@ -258,13 +258,14 @@ RT_DEV HitRec closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, Count
         } else if (cur != RT_EMPTY_LEAF) {
             uint32_t i = cur & ~RT_LEAF_BIT;
             for (;;) {
-                TriIsect T = load_isect(S.tri_isect + i);
+                TriIsect T = load_isect(S.tri_walk + i);
                 if (COUNT) cnt.tris++;
                 float t, u, v; bool inside;
-                if (tri_test(T, o, d, t, u, v, inside) && (t < best.t || (t == best.t && (int)i < best.idx))) {
-                    best.t = t; best.u = u; best.v = v; best.inside = inside; best.idx = (int)i;
+                const int fi = (int)(T.pad >> 1); // index in the figure order
+                if (tri_test(T, o, d, t, u, v, inside) && (t < best.t || (t == best.t && fi < best.idx))) {
+                    best.t = t; best.u = u; best.v = v; best.inside = inside; best.idx = fi;
                 }
-                if (T.pad) break; // last triangle of this leaf
+                if (T.pad & 1u) break; // last triangle of this leaf
                 i++;
             }
         }

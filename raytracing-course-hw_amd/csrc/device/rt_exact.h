@@ -15,8 +15,8 @@ namespace dev {
 // hit word of a path record: 0xFFFFFFFF = miss, else figure index | flags; packed word: see rt_wavefront.h
 #define WF_MISS 0xFFFFFFFFu
 #define WF_INSIDE_BIT 0x40000000u
-#define WF_NEAR_TIE_BIT 0x80000000u   // another triangle was hit within a few ulp of the best t (never set on WF_MISS)
-#define WF_INDEX_MASK 0x3FFFFFFFu
+#define WF_GAP_SHIFT 24               // bits 24..29: how far behind the hit the runner-up lies, as a power of two of t (pt_gap_code); bit 31 stays 0 on a hit
+#define WF_INDEX_MASK 0x00FFFFFFu     // figure index: the hw8 / hw7 path takes scenes of up to 2^24 - 1 triangles
 #define WF_SAMPLE_MASK 0x01FFFFFFu    // 25 bits of sample index in the packed word
 #define WF_VERIFIED_BIT 0x80000000u   // packed word: the hit in q2 comes from the reference-exact walk
 
@@ -129,6 +129,54 @@ RT_DEV bool pt_box_robust(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
     const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
     const float exit_ = t + fminf(fminf(bx, by), bz);
     return worst >= need && exit_ >= need; // NaN compares false: not robust
+}
+
+// The reference prunes a subtree whose box the ray enters behind the best hit so far (bvh.h:118: curBest < t_box).  That is harmless
+// for a hit that lies inside its triangle's box -- but the reference's triangle test solves only two projected equations
+// (primitives.cpp:85-104), and for a triangle whose plane is nearly parallel to the projection's kernel it accepts points well outside
+// the triangle, even outside its box (a "hit" 0.005 in front of the box of a sphere triangle 0.1 across, on the benchmark scene).
+// Such a hit X is found by the reference only if no other hit Y with t_Y < (entry of X's box) came first, and the same goes, within
+// rounding, for a hit that lies IN a face of its box (axis-aligned triangles: flat boxes; the rounding is absolute, so for the
+// short rays that start on a wall and point into it the window is a tenth of t).  So the walkers report the best hit and how far
+// behind it the runner-up lies, and the hit goes to the exact walk when the runner-up is within
+//     window = max_k (rounded entry of slab k) - t = c1 t - min_k a_k,     a_k = (in_k - c2) / |d_k|   (terms of pt_box_robust)
+// (in_k: distance from the hit point back to the entry face of slab k, negative when the point is outside) or within the plain tie
+// tolerance of 4 ulp.  To see the runner-up whatever tree they walk, the walkers prune boxes and drop farther hits only beyond
+// best_t + max(cull_k best_t, window): the relative part (SceneView::cull_k = 2^-7) is what lets them find a BETTER hit of the first
+// kind, whose box lies behind the hit they hold.
+// The runner-up's distance behind the hit travels in six bits of the hit word: code c > 0 means (t2 - t) / t >= 2^(c - 41),
+// c = 0 means "no farther than 2^-40 t" (or equal); the gate works with that floor (at most 2x too cautious).
+RT_DEV uint32_t pt_gap_code(float t, float t2) {
+    const float r = (t2 - t) / t;
+    if (!(r > 0.f)) return 0u;
+    const int c = (int)(__float_as_uint(r) >> 23) - 127 + 41;
+    return (uint32_t)(c < 0 ? 0 : (c > 63 ? 63 : c)) << WF_GAP_SHIFT;
+}
+RT_DEV float pt_gap_floor(uint32_t hit, float t) {
+    const uint32_t c = (hit >> WF_GAP_SHIFT) & 63u;
+    return c ? __uint_as_float((c - 41u + 127u) << 23) * t : 0.f;
+}
+// Absolute part of the walkers' look-behind: the window of a hit that lies inside its box (in_k >= 0) is at most c1 t + c2 max_k 1/|d_k|.
+RT_DEV float pt_look_behind_abs(F3 d, float c2) {
+    return 1.25f * c2 / fmaxf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), 1e-30f);
+}
+// The gate: does the walkers' hit (t, runner-up at t2) stand as the reference's answer?  Yes when every box above it passes the
+// reference's test robustly (pt_box_robust), the runner-up lies beyond the hit's window and beyond the tie tolerance, and the window
+// does not reach past what the walkers looked at (a hit reported well in front of its own box).
+RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2, float cull_k) {
+    const F3 P = o + t * d;
+    const float ix = 1.0f / fmaxf(fabsf(d.x), 1e-30f), iy = 1.0f / fmaxf(fabsf(d.y), 1e-30f), iz = 1.0f / fmaxf(fabsf(d.z), 1e-30f);
+    const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
+    const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
+    const float inz = d.z > 0 ? P.z - lo.z : hi.z - P.z, outz = d.z > 0 ? hi.z - P.z : P.z - lo.z;
+    const float ax = (inx - c2) * ix, ay = (iny - c2) * iy, az = (inz - c2) * iz;
+    const float bx = (outx - c2) * ix, by = (outy - c2) * iy, bz = (outz - c2) * iz;
+    const float need = 1.9073486328125e-06f * t;
+    const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
+    const float exit_ = t + fminf(fminf(bx, by), bz);
+    const float window = need - fminf(fminf(ax, ay), az);
+    const float seen = fmaxf(cull_k * t, 1.25f * c2 * fmaxf(fmaxf(ix, iy), iz));   // the walkers' look-behind for this ray and t
+    return worst >= need && exit_ >= need && gap > window && gap > 4.8e-7f * (t + gap) && window <= seen; // NaN compares false: exact walk
 }
 
 // light_pdf_one (rt_device.h) that also says whether the hit is robust against the reference's box tests (pt_box_robust on

@@ -89,6 +89,9 @@ struct PtParams {
     unsigned long long deadline_ticks; // 100 MHz ticks a wave may spend in this launch before it gives up (error)
     unsigned long long *counters;     // [0] closest-hit queries, [1] light queries, [2] node visits, [3] triangle tests, [10] discarded speculative hits, [12] exact closest hits, [13] exact light sums, [14] waves that gave up waiting (error)
     unsigned long long *debug;        // nullable: per workgroup {start time, exit time of its last wave (100 MHz ticks), paths}
+    // COUNT builds, RTAMD_TRACE_PIXEL: every hit record the shader consumes for pixel trace_pixel (= y * width + x) is appended as
+    // four float4 (r0..r3 of the path record: ray, hit, packed word); word 0 of trace_buf counts the entries
+    float4 *trace_buf; uint32_t trace_cap; int32_t trace_pixel;
 };
 
 // COUNT builds only: where a wave's time goes (shader-clock cycles per role) and how full its walker iterations are
@@ -180,12 +183,18 @@ template <bool COUNT>
 RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
-    bool active = false, tie = false, refill_ok = true;
+    bool active = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
     int sp = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
+    // Boxes are pruned, and farther hits dropped, only beyond cull_t = best_t + the look-behind of rt_exact.h: the runner-up of the
+    // best hit must be SEEN, whatever tree the walk uses, to decide at the end of the walk whether the exact walk is needed.
+    float cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // h_ray: absolute part of the look-behind (pt_look_behind)
+    auto store_hit = [&]() { // the gate (pt_shade_item) decides with the runner-up's t whether this hit needs the exact walk
+        wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(S.exact_boxes && hit != WF_MISS ? hit | pt_gap_code(best_t, t2) : hit));
+    };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
@@ -208,7 +217,8 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = make_ray_inv(o, d);
-                    cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; tie = false;
+                    h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2) : 0.f;
+                    cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                     active = true;
                 }
             }
@@ -229,8 +239,8 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
-                bool h0 = slab_test(lo0, hi0, ray, best_t, n0);
-                bool h1 = slab_test(lo1, hi1, ray, best_t, n1);
+                bool h0 = slab_test(lo0, hi0, ray, cull_t, n0);
+                bool h1 = slab_test(lo1, hi1, ray, cull_t, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) {
                     bool swap = n1 < n0;
@@ -239,7 +249,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 } else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) {
-                    wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
+                    store_hit();
                     active = false; fin = l;
                 } else cur = stack[--sp][lane];
             }
@@ -248,25 +258,24 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (cur != RT_EMPTY_LEAF) {
                 uint32_t i = cur & ~RT_LEAF_BIT;
                 for (;;) {
-                    TriIsect T = load_isect(S.tri_isect + i);
+                    TriIsect T = load_isect(S.tri_walk + i);
                     if (COUNT) n_tris++;
                     float t, u, v; bool inside;
-                    if (tri_test_closer(T, o, d, best_t, t, u, v, inside)) {
-                        // a second hit within the slab test's own tolerance of the best one: the reference's pruning may
-                        // order the two differently (bvh.h:118), so the exact walk decides
-                        const bool close = fabsf(t - best_t) <= 4.8e-7f * fmaxf(t, best_t);
+                    const uint32_t fi = T.pad >> 1; // index in the figure order
+                    if (tri_test_closer(T, o, d, cull_t, t, u, v, inside)) {
                         const uint32_t best_i = hit & WF_INDEX_MASK;
-                        if (t < best_t || (t == best_t && i < best_i)) {
-                            tie = close && hit != WF_MISS;
-                            best_t = t; best_u = u; best_v = v; hit = i | (inside ? WF_INSIDE_BIT : 0u);
-                        } else tie = tie || close;
+                        if (t < best_t || (t == best_t && fi < best_i)) { // reference tie rule: smallest t, equal t -> lowest figure index
+                            t2 = fminf(t2, best_t);
+                            best_t = t; best_u = u; best_v = v; hit = fi | (inside ? WF_INSIDE_BIT : 0u);
+                            cull_t = t + fmaxf(S.cull_k * t, h_ray);
+                        } else t2 = fminf(t2, t);
                     }
-                    if (T.pad) break;
+                    if (T.pad & 1u) break;
                     i++;
                 }
             }
             if (sp == 0) {
-                wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
+                store_hit();
                 active = false; fin = l;
             } else cur = stack[--sp][lane];
         }
@@ -514,6 +523,16 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
             int todo = 0;
             bool discarded = false;
+            if (COUNT && P.trace_buf && got != PT_NONE) {
+                const uint32_t tslot = pt_slot(sh, got);
+                int tx, ty; bool tin; size_t toi;
+                wf_slot_to_pixel(R, tslot + W.slot_base, tx, ty, tin, toi);
+                if (tin && ty * R.width + tx == P.trace_pixel) {
+                    const float4 *tr = wf_rec(W, tslot);
+                    const uint32_t k = atomicAdd(reinterpret_cast<uint32_t *>(P.trace_buf), 1u);
+                    if (4u * k + 5u <= P.trace_cap) for (int q = 0; q < 4; q++) P.trace_buf[1 + 4 * k + q] = tr[q];
+                }
+            }
             if (got != PT_NONE) todo = pt_shade_item<FEAT>(S, R, W, pt_slot(sh, got), discarded);
             n_discarded += __popcll(__ballot(discarded));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -27,7 +27,8 @@ struct TriIsect {
     float a1, b1;       // magic1 . b, magic1 . c
     float a2, b2;       // magic2 . b, magic2 . c
     float den;          // b1*a2 - a1*b2
-    uint32_t pad;
+    uint32_t pad;       // triangle arrays: bit 0 = last record of its leaf, bits 1.. = the triangle's index in the figure order (what a hit
+                        // reports and the tie rule compares); light arrays: 1 = last record of its leaf
 };
 static_assert(sizeof(TriIsect) == 48, "TriIsect must be 48 bytes");
 
@@ -77,7 +78,9 @@ struct GpuImage {
 // Device-side view of a prepared scene (pointers into HBM).
 struct SceneView {
     const GpuNode *nodes;          // scene BVH, root = 0
-    const TriIsect *tri_isect;
+    const TriIsect *tri_isect;     // figure order (the reference's BVH order; LOAD order under RT_BUILD_DEVICE_BVH): shading, exact walks
+    float cull_k;                  // walkers prune boxes against best_t (1 + cull_k): the tie tolerance of the leaf test plus the slab test's rounding
+    const TriIsect *tri_walk;      // the same records in the leaf order of `nodes` (== tri_isect when `nodes` is the reference topology)
     const TriShade *tri_shade;
     const GpuNode *light_nodes;    // light BVH in the reference's topology, root = 0
     const LightRec *lights;

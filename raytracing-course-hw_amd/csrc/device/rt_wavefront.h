@@ -39,7 +39,7 @@ namespace dev {
 // Stack entry (2 x float4): E0 = emission.xyz, pdf (cosine + vndf terms; the light loop adds its term)
 //                           E1 = brdf (then mult).xyz, dot(d, n_s)
 struct WfView {
-    float4 *r0;             // per slot: `stride` float4 = 4 (R0 record) + 2 per stack level, contiguous
+    float4 *r0;             // per slot: `stride` float4 = WF_REC_BASE (R0 record) + 2 per stack level, contiguous
     uint32_t stride;
     uint32_t *q_trace[2];
     uint32_t *q_light;
@@ -51,7 +51,8 @@ struct WfView {
 };
 
 RT_DEV float4 *wf_rec(const WfView &W, uint32_t slot) { return W.r0 + (size_t)slot * W.stride; }
-RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0 + (size_t)slot * W.stride + 4 + 2 * level; }
+#define WF_REC_BASE 4          // float4 in front of the per-level entries: q0..q3 (16 float4 = two 128-byte lines per path at depth 6)
+RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0 + (size_t)slot * W.stride + WF_REC_BASE + 2 * level; }
 
 #define WF_CTR 8               // counter words per round
 #ifndef WF_STACK
@@ -279,8 +280,13 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
     int sp = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
-    bool tie = false; // another triangle hit within the slab test's tolerance of the best one: the exact walk decides (rt_exact.h)
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
+    // Boxes are pruned, and farther hits dropped, only beyond cull_t = best_t + the look-behind of rt_exact.h: the runner-up of the
+    // best hit must be SEEN, whatever tree the walk uses, to decide at the end of the walk whether the exact walk is needed.
+    float cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // h_ray: absolute part of the look-behind (pt_look_behind)
+    auto store_hit = [&]() { // the gate (pt_shade_item) decides with the runner-up's t whether this hit needs the exact walk
+        wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(S.exact_boxes && hit != WF_MISS ? hit | pt_gap_code(best_t, t2) : hit));
+    };
     unsigned long long n_nodes = 0, n_tris = 0;
     unsigned long long w_node_iters = 0, w_leaf_phases = 0, w_leaf_lanes = 0, w_refills = 0; // wave-level (lane 0 reports)
     uint32_t w_iter = 0, ray_start = 0; // COUNT: wave iterations a ray stays in flight -> histogram counters[16 + min(15, iterations / 32)]
@@ -297,7 +303,8 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 float4 q0 = r[0], q1 = r[1];
                 o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                 ray = make_ray_inv(o, d);
-                cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; tie = false;
+                h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2) : 0.f;
+                cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                 active = true;
                 if (COUNT) ray_start = w_iter;
             }
@@ -318,8 +325,8 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
-                bool h0 = slab_test(lo0, hi0, ray, best_t, n0);
-                bool h1 = slab_test(lo1, hi1, ray, best_t, n1);
+                bool h0 = slab_test(lo0, hi0, ray, cull_t, n0);
+                bool h1 = slab_test(lo1, hi1, ray, cull_t, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) {
                     bool swap = n1 < n0;
@@ -328,7 +335,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 } else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) { // traversal finished: publish the hit
-                    wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
+                    store_hit();
                     active = false;
                     if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
                 } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
@@ -341,23 +348,24 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
             if (cur != RT_EMPTY_LEAF) {
                 uint32_t i = cur & ~RT_LEAF_BIT;
                 for (;;) {
-                    TriIsect T = load_isect(S.tri_isect + i);
+                    TriIsect T = load_isect(S.tri_walk + i);
                     if (COUNT) n_tris++;
                     float t, u, v; bool inside;
-                    if (tri_test_closer(T, o, d, best_t, t, u, v, inside)) {
-                        const bool close = fabsf(t - best_t) <= 4.8e-7f * fmaxf(t, best_t);
+                    const uint32_t fi = T.pad >> 1; // index in the figure order
+                    if (tri_test_closer(T, o, d, cull_t, t, u, v, inside)) {
                         const uint32_t best_i = hit & WF_INDEX_MASK;
-                        if (t < best_t || (t == best_t && i < best_i)) {
-                            tie = close && hit != WF_MISS;
-                            best_t = t; best_u = u; best_v = v; hit = i | (inside ? WF_INSIDE_BIT : 0u);
-                        } else tie = tie || close;
+                        if (t < best_t || (t == best_t && fi < best_i)) { // reference tie rule: smallest t, equal t -> lowest figure index
+                            t2 = fminf(t2, best_t);
+                            best_t = t; best_u = u; best_v = v; hit = fi | (inside ? WF_INSIDE_BIT : 0u);
+                            cull_t = t + fmaxf(S.cull_k * t, h_ray);
+                        } else t2 = fminf(t2, t);
                     }
-                    if (T.pad) break;
+                    if (T.pad & 1u) break;
                     i++;
                 }
             }
             if (sp == 0) {
-                wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(hit | (tie && hit != WF_MISS ? WF_NEAR_TIE_BIT : 0u)));
+                store_hit();
                 active = false;
                 if (COUNT && hist) { uint32_t b = (w_iter - ray_start) >> 5; atomicAdd(&counters[16 + (b > 15u ? 15u : b)], 1ull); }
             } else cur = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
@@ -752,15 +760,11 @@ RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &
         const uint32_t hit = __float_as_uint(q2.w);
         const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
         if (hit != WF_MISS && !(packed & WF_VERIFIED_BIT)) {
-            bool robust = !(hit & WF_NEAR_TIE_BIT);
-            if (robust) {
-                const float4 q0 = r[0], q1 = r[1];
-                const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
-                const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
-                const float4 lo = bx[0], hi = bx[1];
-                robust = pt_box_robust(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), o + q2.x * d, d, q2.x, S.box_c2);
-            }
-            if (!robust) return PT_SHADE_EXACT;
+            const float4 q0 = r[0], q1 = r[1];
+            const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+            const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
+            const float4 lo = bx[0], hi = bx[1];
+            if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), o, d, q2.x, pt_gap_floor(hit, q2.x), S.box_c2, S.cull_k)) return PT_SHADE_EXACT;
         }
     }
     return wf_shade_item<FEAT>(S, R, W, slot, counters, &discarded);

@@ -15,11 +15,12 @@ struct DeviceTree {
 };
 
 // d_boxes: 8 floats per primitive (lo.xyz, -, hi.xyz, -) on the current device; n >= 1.  Synchronous.  Throws HipError.
-DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n);
+// abs_pad: absolute part of the node boxes' padding (scene_prep.cpp pad_box).
+DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad);
 void free_device_tree(DeviceTree &t);
 
-// out[i] = in[order[i]] for records of elem_bytes (a multiple of 16); then the 32-bit word at mark_word_offset of every record whose
-// slot is the last of its leaf is set to 1 (mark_word_offset < 0: no marks).
-void gather_records(const void *d_in, void *d_out, const DeviceTree &t, uint32_t n, uint32_t elem_bytes, int mark_word_offset);
+// out[i] = in[order[i]] for records of elem_bytes (a multiple of 16); then the 32-bit word at mark_word_offset of every record becomes
+// 1 / 0 (last slot of its leaf or not), or, with or_into_word, keeps its value and gets the mark in bit 0 (mark_word_offset < 0: no marks).
+void gather_records(const void *d_in, void *d_out, const DeviceTree &t, uint32_t n, uint32_t elem_bytes, int mark_word_offset, bool or_into_word = false);
 
 } // namespace rtamd

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <stdexcept>
 #include <thread>
@@ -133,21 +134,32 @@ private:
     }
 };
 
-// Conservative padding for the kernel's reciprocal-multiply slab test: 2^-17 relative to the
-// coordinate magnitude (64 ulp) on every face.
-inline void pad_box(const Box3 &b, float lo[3], float hi[3]) {
+// Conservative padding for the kernels' reciprocal-multiply slab test: 2^-17 relative to the coordinate magnitude (64 ulp) on every
+// face, plus abs_pad = 2^-18 x the largest |coordinate| of scene and camera.  The absolute part is what makes the walk independent of
+// the tree: a triangle test accepts points up to a few ulp OF THE LARGEST COORDINATES INVOLVED outside the true triangle (p = o + t d),
+// so a hit on an edge that lies in a box face at a small coordinate (x = 0: relative padding vanishes) must not be pruned by one
+// tree's boxes and kept by another's — the near-tie flags of the walkers (WF_NEAR_TIE_BIT) rely on every such hit being seen.
+inline void pad_box(const Box3 &b, float lo[3], float hi[3], float abs_pad) {
     for (int k = 0; k < 3; k++) {
         float mag = smax(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
-        float pad = mag * 7.62939453125e-06f + 1e-30f;
+        float pad = mag * 7.62939453125e-06f + abs_pad + 1e-30f;
         lo[k] = b.lo[k] - pad;
         hi[k] = b.hi[k] + pad;
     }
+}
+inline float scene_abs_pad(const std::vector<Box3> &boxes, const rt_camera &cam) {
+    float m = 0.f;
+    for (int k = 0; k < 3; k++) m = smax(m, std::fabs(cam.position[k]));
+    for (const Box3 &b : boxes) for (int k = 0; k < 3; k++) m = smax(m, smax(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+    float scale = 1.f;
+    if (const char *e = getenv("RTAMD_BOX_PAD_SCALE")) scale = (float)atof(e); // experiments
+    return m * 3.814697265625e-06f * scale; // 2^-18
 }
 
 // Re-encode a reference tree as two-box GpuNodes (child reference: inner node index, or
 // 0x80000000|first for a leaf, 0xFFFFFFFF for an empty leaf).  `leaf_last` receives the index of
 // the last primitive of every leaf; the kernels walk a leaf until they meet that mark.
-void encode_tree(const std::vector<RefNode> &ref, std::vector<GpuNode> &out, std::vector<uint32_t> &leaf_last) {
+void encode_tree(const std::vector<RefNode> &ref, std::vector<GpuNode> &out, std::vector<uint32_t> &leaf_last, float abs_pad = 0.f) {
     out.clear();
     leaf_last.clear();
     auto empty_child = [](float lo[3], float hi[3], int32_t &child, int32_t &cnt) {
@@ -167,7 +179,7 @@ void encode_tree(const std::vector<RefNode> &ref, std::vector<GpuNode> &out, std
     }
     if (ref[0].left == 0) { // root is a leaf: wrap it
         GpuNode g;
-        pad_box(ref[0].box, g.lo0, g.hi0);
+        pad_box(ref[0].box, g.lo0, g.hi0, abs_pad);
         leaf_ref(ref[0], g.child0, g.cnt0);
         empty_child(g.lo1, g.hi1, g.child1, g.cnt1);
         out.push_back(g);
@@ -183,8 +195,8 @@ void encode_tree(const std::vector<RefNode> &ref, std::vector<GpuNode> &out, std
         if (ref[i].left == 0) continue;
         GpuNode &g = out[gpu_index[i]];
         const RefNode &l = ref[ref[i].left], &r = ref[ref[i].right];
-        pad_box(l.box, g.lo0, g.hi0);
-        pad_box(r.box, g.lo1, g.hi1);
+        pad_box(l.box, g.lo0, g.hi0, abs_pad);
+        pad_box(r.box, g.lo1, g.hi1, abs_pad);
         if (l.left == 0) leaf_ref(l, g.child0, g.cnt0);
         else { g.child0 = gpu_index[ref[i].left]; g.cnt0 = 0; }
         if (r.left == 0) leaf_ref(r, g.child1, g.cnt1);
@@ -292,7 +304,7 @@ static void build_light_sep(const std::vector<RefNode> &rn, uint32_t nl, std::ve
 
 void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_device) {
     const uint32_t n = d.n_triangles;
-    if (n >= 0x7FFFFFFFu) throw std::runtime_error("too many triangles (limit 2^31-2)");
+    if (n >= 0x00FFFFFFu) throw std::runtime_error("too many triangles (limit 2^24-2: the hit word keeps 24 bits of figure index, device/rt_exact.h)");
     if (n && (!d.positions || !d.material_index)) throw std::runtime_error("scene has triangles but no positions/material_index");
     for (uint32_t i = 0; i < n; i++)
         if (d.material_index[i] >= d.n_materials) throw std::runtime_error("triangle material index out of range");
@@ -312,6 +324,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
     out.figure_order.resize(n);
     for (uint32_t i = 0; i < n; i++) out.figure_order[i] = i;
     std::vector<uint32_t> scene_leaf_last, light_leaf_last;
+    out.box_pad = scene_abs_pad(boxes, d.camera);
     if (tree_on_device) {
         // RT_BUILD_DEVICE_BVH: no replay of the reference's builder -- the figure order is the LOAD order, the records below stay in
         // it (tri_box doubles as the builder's input) and rtamd_build.hip makes the tree and the leaf order on the GPU
@@ -322,8 +335,17 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
         scene_builder.run(n);
         out.bvh_depth = scene_builder.depth;
         out.n_ref_nodes = (uint32_t)scene_builder.nodes.size();
-        encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
+        encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last, out.box_pad);
         bfs_top_first(out.nodes, 512);
+        // Walk boxes: the box of the figure's reference leaf (a few leaves hold several triangles): whatever the reference can reach
+        // through its leaf box is then inside a box of ours.  (Widening each box by how far outside the triangle the reference's test
+        // can still report a hit -- delta cot(phi), rt_exact.h -- was tried: the few triangles whose plane contains the projection's
+        // kernel get scene-sized boxes, their test accepts a sliver of every ray, and 12 % of the queries end in the exact walk.)
+        out.walk_box.assign((size_t)(n ? n : 1) * 8, 0.f);
+        for (const RefNode &rn : scene_builder.nodes)
+            if (rn.left == 0)
+                for (uint32_t i = rn.first; i < rn.last; i++)
+                    for (int k = 0; k < 3; k++) { out.walk_box[8 * (size_t)i + k] = rn.box.lo[k]; out.walk_box[8 * (size_t)i + 4 + k] = rn.box.hi[k]; }
         encode_ref_tree(scene_builder.nodes, out.ref_nodes);
     }
 
@@ -337,7 +359,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
     RefBuilder light_builder(keys, boxes, lorder);
     light_builder.run(n_lights);
     out.light_bvh_depth = light_builder.depth;
-    encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last, out.box_pad);
     encode_ref_tree(light_builder.nodes, out.ref_light_nodes);
     build_light_sep(light_builder.nodes, n_lights, out.light_sep, out.light_sep_levels);
     out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
@@ -356,6 +378,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
             max_coord = smax(max_coord, smax(std::fabs(boxes[src].lo[k]), std::fabs(boxes[src].hi[k])));
         }
         out.isect[i] = make_isect(d.positions + 9 * (size_t)src);
+        out.isect[i].pad = i << 1; // figure index; bit 0 (last of its leaf) is set below / by the GPU builder's gather
         TriShade &s = out.shade[i];
         memset(&s, 0, sizeof s);
         if (d.normals) {
@@ -375,7 +398,7 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
         s.orig = src;
     }
     out.box_c2 = max_coord * 9.5367431640625e-07f; // 2^-20
-    for (uint32_t i : scene_leaf_last) out.isect[i].pad = 1;
+    for (uint32_t i : scene_leaf_last) out.isect[i].pad |= 1u;
     out.lights.resize(n_lights);
     for (uint32_t i = 0; i < n_lights; i++) {
         uint32_t src = out.light_order[i];
@@ -473,7 +496,8 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on
     light_builder.run(n_lights);
     out.light_bvh_depth = light_builder.depth;
     std::vector<uint32_t> light_leaf_last, scene_leaf_last;
-    encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    out.box_pad = scene_abs_pad(boxes, d.camera);
+    encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last, out.box_pad);
     out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
     // 3. own scene tree: the same full-sweep SAH builder keyed on the data3 vertex (as hw8 does) -- or, when the caller builds the
     //    tree on the GPU (device/rt_bvh_build.h), the records stay in LOAD order and the boxes go along
@@ -487,7 +511,7 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on
         RefBuilder mine(keys, boxes, my_order);
         mine.run(n);
         out.bvh_depth = mine.depth;
-        encode_tree(mine.nodes, out.nodes, scene_leaf_last);
+        encode_tree(mine.nodes, out.nodes, scene_leaf_last, out.box_pad);
     }
     auto make = [&](uint32_t src) {
         const float *p = d.positions + 9 * (size_t)src;
@@ -517,7 +541,7 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on
         fast.run(n_lights);
         out.fast_light_bvh_depth = fast.depth;
         std::vector<uint32_t> fast_leaf_last;
-        encode_tree(fast.nodes, out.fast_light_nodes, fast_leaf_last);
+        encode_tree(fast.nodes, out.fast_light_nodes, fast_leaf_last, out.box_pad);
         out.fast_lights.resize(n_lights);
         std::vector<uint32_t> light_pos(n, 0);
         for (uint32_t i = 0; i < n_lights; i++) light_pos[out.light_order[i]] = i;

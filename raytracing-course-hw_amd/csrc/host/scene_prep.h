@@ -14,7 +14,12 @@ struct PreparedScene {
     // walks of the persistent pipeline read (device/rt_persistent.h); box_c2 = 2^-20 * the largest |coordinate| of scene and camera.
     std::vector<GpuRefNode> ref_nodes, ref_light_nodes;
     std::vector<float> tri_box;
+    // Per figure the box of its LEAF in the reference's tree (a few leaves hold several triangles): what the GPU builder makes the
+    // walkers' tree from, so that whatever the reference can reach through its leaf box is inside a box of ours.  Empty when the
+    // reference's tree is not replayed.
+    std::vector<float> walk_box;
     float box_c2 = 0.f;
+    float box_pad = 0.f;   // absolute part of the walkers' box padding (scene_prep.cpp pad_box): 2^-18 x the largest |coordinate|
     // Order of the light-pdf additions without walking the reference tree: light_sep[j * n_lights + i] = the shallowest
     // separation depth among the boundaries i .. i + 2^j - 1 (boundary b lies between lights b and b+1 of the reference order;
     // its depth is that of the reference-tree node whose children hold the two lights, or, inside one leaf, a pseudo depth
@@ -47,6 +52,7 @@ struct PreparedScene6 {
     std::vector<uint32_t> light_ref; // 4 words per reference light-tree node: left, right, first, last
     std::vector<uint16_t> light_sep; // as PreparedScene::light_sep, over the reference light tree of hw6
     std::vector<float> boxes8;       // tree_on_device only
+    float box_pad = 0.f;             // as PreparedScene::box_pad
     uint32_t light_sep_levels = 0;
     std::vector<GpuMaterial6> materials;
     std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index

@@ -240,7 +240,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                 DeviceTree t;
                 Tri6 *d_tris = nullptr;
                 try {
-                    t = build_tree_on_device(d_boxes, desc->n_triangles);
+                    t = build_tree_on_device(d_boxes, desc->n_triangles, P6.box_pad);
                     HIP_CHECK(hipMalloc((void **)&d_tris, (size_t)desc->n_triangles * sizeof(Tri6)));
                     gather_records(d_load, d_tris, t, desc->n_triangles, sizeof(Tri6), 13); // word 13 = Tri6::last
                     HIP_CHECK(hipDeviceSynchronize());
@@ -300,48 +300,55 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             return RT_OK;
         }
         if (desc->build_flags & ~RT_BUILD_DEVICE_BVH) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: unknown build_flags");
-        const bool tree_on_device = (desc->build_flags & RT_BUILD_DEVICE_BVH) && desc->n_triangles >= 64; // a handful of triangles: the host builder (same contract: it then runs on the LOAD order's keys)
+        // Two things a scene tree is needed for.  The replay needs the reference's FIGURE ORDER (tie rule, light numbering) and, for the
+        // rare hits at a box boundary, the reference's own tree (exact walks): the host replays the reference's builder for those
+        // (prepare_scene) unless RT_BUILD_DEVICE_BVH gives the order up.  The walkers need a good tree of bounded depth, and a closest
+        // hit does not depend on which: that one is built on the GPU (device/rt_bvh_build.h) over the records in figure order, each of
+        // which carries its figure index (RTAMD_HOST_BVH=1, or a handful of triangles: the walkers use the reference topology).
+        const bool fast_build = (desc->build_flags & RT_BUILD_DEVICE_BVH) && desc->n_triangles >= 64;
+        const bool walk_tree_on_device = desc->n_triangles >= 64 && (fast_build || !getenv("RTAMD_HOST_BVH"));
         PreparedScene P;
-        prepare_scene(*desc, P, tree_on_device);
+        prepare_scene(*desc, P, fast_build);
         double t1 = now_ms();
         uint64_t bytes = 0;
         SceneView &V = s->view;
         auto keep = [&](auto *p) { s->allocations.push_back((void *)p); return p; };
-        if (tree_on_device) {
+        V.tri_isect = keep(upload(P.isect, bytes));
+        V.tri_shade = keep(upload(P.shade, bytes));
+        V.tri_box = keep(upload(P.tri_box, bytes));
+        uint32_t ref_depth = P.bvh_depth;
+        if (walk_tree_on_device) {
             const uint32_t n = desc->n_triangles;
-            TriIsect *d_isect = upload(P.isect, bytes), *o_isect = nullptr;
-            TriShade *d_shade = upload(P.shade, bytes), *o_shade = nullptr;
-            float *d_box = upload(P.tri_box, bytes), *o_box = nullptr;
             DeviceTree t;
+            TriIsect *d_walk = nullptr;
             try {
-                t = build_tree_on_device(d_box, n);
-                HIP_CHECK(hipMalloc((void **)&o_isect, (size_t)n * sizeof(TriIsect)));
-                HIP_CHECK(hipMalloc((void **)&o_shade, (size_t)n * sizeof(TriShade)));
-                HIP_CHECK(hipMalloc((void **)&o_box, (size_t)n * 32));
-                gather_records(d_isect, o_isect, t, n, sizeof(TriIsect), 11); // word 11 = TriIsect::pad, the leaf mark
-                gather_records(d_shade, o_shade, t, n, sizeof(TriShade), -1);
-                gather_records(d_box, o_box, t, n, 32, -1);
+                if (!P.walk_box.empty()) { // reference leaf boxes (scene_prep.h)
+                    uint64_t scratch = 0;
+                    float *d_walk_box = upload(P.walk_box, scratch);
+                    try { t = build_tree_on_device(d_walk_box, n, P.box_pad); } catch (...) { (void)hipFree(d_walk_box); throw; }
+                    (void)hipFree(d_walk_box);
+                } else t = build_tree_on_device(V.tri_box, n, P.box_pad);
+                HIP_CHECK(hipMalloc((void **)&d_walk, (size_t)n * sizeof(TriIsect)));
+                gather_records(V.tri_isect, d_walk, t, n, sizeof(TriIsect), 11, true); // word 11 = TriIsect::pad: figure index << 1 | leaf mark
                 HIP_CHECK(hipDeviceSynchronize());
             } catch (...) {
-                (void)hipFree(d_isect); (void)hipFree(d_shade); (void)hipFree(d_box);
-                if (o_isect) (void)hipFree(o_isect); if (o_shade) (void)hipFree(o_shade); if (o_box) (void)hipFree(o_box);
+                if (d_walk) (void)hipFree(d_walk);
                 free_device_tree(t);
                 throw;
             }
-            (void)hipFree(d_isect); (void)hipFree(d_shade); (void)hipFree(d_box);
             (void)hipFree(t.order); (void)hipFree(t.last); t.order = nullptr; t.last = nullptr;
-            V.nodes = keep(t.nodes); V.tri_isect = keep(o_isect); V.tri_shade = keep(o_shade); V.tri_box = keep(o_box);
-            bytes += (uint64_t)t.n_nodes * sizeof(GpuNode);
+            V.nodes = keep(t.nodes); V.tri_walk = keep(d_walk);
+            bytes += (uint64_t)t.n_nodes * sizeof(GpuNode) + (uint64_t)n * sizeof(TriIsect);
             P.bvh_depth = t.depth;
             P.nodes.resize(t.n_nodes);
             s->info.bvh_build_ms = t.build_ms; s->info.bvh_on_device = 1;
-            s->device_tree = true;
+            s->device_tree = fast_build;
         } else {
             V.nodes = keep(upload(P.nodes, bytes));
-            V.tri_isect = keep(upload(P.isect, bytes));
-            V.tri_shade = keep(upload(P.shade, bytes));
-            V.tri_box = keep(upload(P.tri_box, bytes));
+            V.tri_walk = V.tri_isect;
         }
+        if (ref_depth > RT_STACK_SIZE - 2) // the exact walks keep a private stack over the reference's own tree
+            return fail(RT_ERR_LIMIT, "the reference's scene BVH is deeper than the exact walk's stack (" + std::to_string(ref_depth) + ")");
         if (P.bvh_depth > RT_STACK_SIZE - 2 || P.light_bvh_depth > RT_STACK_SIZE - 2)
             return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P.bvh_depth) + "/" +
                                           std::to_string(P.light_bvh_depth) + ")");
@@ -350,7 +357,9 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         V.ref_nodes = keep(upload(P.ref_nodes, bytes));
         V.ref_light_nodes = keep(upload(P.ref_light_nodes, bytes));
         V.box_c2 = P.box_c2;
-        V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || tree_on_device) ? 0u : 1u; // no reference tree to be exact about in a device-built scene
+        // how far behind the best hit the walkers still look, relative to t (rt_exact.h)
+        V.cull_k = getenv("RTAMD_CULL_K") ? (float)atof(getenv("RTAMD_CULL_K")) : 0.0078125f;
+        V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || fast_build) ? 0u : 1u; // RT_BUILD_DEVICE_BVH: there is no reference tree to be exact about
         V.lights = keep(upload(P.lights, bytes));
         V.materials = keep(upload(P.materials, bytes));
         V.images = keep(upload(P.images, bytes));
@@ -497,7 +506,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
     if (scene->wf_slots < n_slots || scene->wf_levels < (size_t)R.ray_depth || scene->wf_ctr_words < ctr_block * pipes) {
         scene->free_wf();
         auto alloc = [&](size_t bytes) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); scene->wf_allocs.push_back(p); return p; };
-        scene->wf.r0 = (float4 *)alloc(n_slots * (64 + 32 * (size_t)R.ray_depth));
+        scene->wf.r0 = (float4 *)alloc(n_slots * (16 * WF_REC_BASE + 32 * (size_t)R.ray_depth));
         scene->wf.q_trace[0] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_trace[1] = (uint32_t *)alloc(n_slots * 4);
         scene->wf.q_light = (uint32_t *)alloc(n_slots * 4);
@@ -551,7 +560,7 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
         }
         HIP_CHECK(hipEventCreateWithFlags(&scene->ev_fork, hipEventDisableTiming));
     }
-    const uint32_t stride = 4u + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
+    const uint32_t stride = (uint32_t)WF_REC_BASE + 2u * (uint32_t)scene->wf_levels; // float4 per slot (the allocation's depth, >= this render's)
     uint32_t first = 0;
     for (int h = 0; h < pipes; h++) {
         const uint32_t groups = n_work / (uint32_t)pipes + ((uint32_t)h < n_work % (uint32_t)pipes ? 1u : 0u);
@@ -664,7 +673,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     if (scene->pt_slots < n_slots || scene->pt_levels < (size_t)R.ray_depth) {
         if (scene->pt_r0) (void)hipFree(scene->pt_r0);
         scene->pt_r0 = nullptr; scene->pt_slots = scene->pt_levels = 0;
-        HIP_CHECK(hipMalloc((void **)&scene->pt_r0, n_slots * (64 + 32 * (size_t)R.ray_depth)));
+        HIP_CHECK(hipMalloc((void **)&scene->pt_r0, n_slots * (16 * WF_REC_BASE + 32 * (size_t)R.ray_depth)));
         scene->pt_slots = n_slots; scene->pt_levels = (size_t)R.ray_depth;
     }
     const size_t group_words = 2 * (size_t)pass_groups + n_blocks_max + 1;
@@ -691,6 +700,17 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
         if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)1024 * 3 * sizeof(unsigned long long)));
         if (n_blocks_max <= 1024) P.debug = scene->d_pt_debug;
     }
+    float4 *d_trace = nullptr;
+    const uint32_t trace_cap = 1u << 16;
+    if (count && getenv("RTAMD_TRACE_PIXEL") && getenv("RTAMD_TRACE_OUT")) { // diagnostic: tools/tuning/trace_pixel.py
+        int tx = 0, ty = 0;
+        if (sscanf(getenv("RTAMD_TRACE_PIXEL"), "%d,%d", &tx, &ty) == 2) {
+            HIP_CHECK(hipMalloc((void **)&d_trace, (size_t)trace_cap * sizeof(float4)));
+            HIP_CHECK(hipMemsetAsync(d_trace, 0, sizeof(float4), stream));
+            P.trace_buf = d_trace; P.trace_cap = trace_cap; P.trace_pixel = ty * R.width + tx;
+        }
+
+    }
     // two phases when there is something to re-deal: enough samples, and several sub-tiles per workgroup
     const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
     const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
@@ -698,7 +718,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes * phases) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     dev::WfView W{};
     W.r0 = scene->pt_r0;
-    W.stride = 4u + 2u * (uint32_t)scene->pt_levels;
+    W.stride = (uint32_t)WF_REC_BASE + 2u * (uint32_t)scene->pt_levels;
     uint32_t first = 0, launch = 0;
     scene->pt_blocks = 0; scene->pt_rebalance_ms = 0; scene->pt_imbalance = 0;
     for (uint32_t p = 0; p < passes; p++) {
@@ -739,6 +759,13 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     HIP_CHECK(hipGetLastError());
     scene->pt_passes = passes;
     scene->pt_launches = launch;
+    if (d_trace) { // diagnostic dump: raw float32, 4 words header (count first), then 16 words per consumed hit record
+        std::vector<float4> h(trace_cap);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpy(h.data(), d_trace, (size_t)trace_cap * sizeof(float4), hipMemcpyDeviceToHost));
+        (void)hipFree(d_trace);
+        if (FILE *f = fopen(getenv("RTAMD_TRACE_OUT"), "wb")) { fwrite(h.data(), sizeof(float4), trace_cap, f); fclose(f); }
+    }
 }
 
 // hw6 in the persistent organisation (device/rt_persistent_hw6.h): passes of up to n_cus x P6_MAX_PATHS path slots, each rendered in
@@ -909,6 +936,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         SceneView V8 = scene->view; // per-render copy: the hw7 replay switches are render parameters, not scene state
         if (hw7) { V8.hw7 = 1; V8.last_level_emission_only = 0; V8.env_image = -1; }
         if (!use_persistent && !getenv("RTAMD_ROUNDS_EXACT")) V8.exact_boxes = 0; // round pipeline and megakernel: the padded box test's answer stands
+        if (!V8.exact_boxes) V8.cull_k = 4.8e-7f; // no exact walks to feed: the walkers look behind the best hit by the tie tolerance only
         uint32_t launches = 0;
         bool time_trace = false, use_persistent6 = false;
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));

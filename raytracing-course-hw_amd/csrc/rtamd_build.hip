@@ -7,21 +7,25 @@
 namespace rtamd {
 
 namespace {
-__global__ void gather16_kernel(const float4 *in, float4 *out, const uint32_t *order, const uint8_t *last, uint32_t n, uint32_t quads, int mark_word) {
+__global__ void gather16_kernel(const float4 *in, float4 *out, const uint32_t *order, const uint8_t *last, uint32_t n, uint32_t quads, int mark_word, bool or_mark) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 *src = in + (size_t)order[i] * quads;
     float4 *dst = out + (size_t)i * quads;
     for (uint32_t q = 0; q < quads; q++) dst[q] = src[q];
-    if (mark_word >= 0) reinterpret_cast<uint32_t *>(dst)[mark_word] = last[i] ? 1u : 0u;
+    if (mark_word >= 0) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(dst) + mark_word;
+        const uint32_t mark = last[i] ? 1u : 0u;
+        *w = or_mark ? ((*w & ~1u) | mark) : mark; // or_mark: the word keeps its upper bits (a leaf mark of another tree in bit 0 is dropped)
+    }
 }
 } // namespace
 
-DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n) {
+DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad) {
     DeviceTree t;
     if (n == 0) throw std::runtime_error("build_tree_on_device: no primitives");
     dev::BvbView B{};
-    B.boxes = d_boxes; B.n = n;
+    B.boxes = d_boxes; B.n = n; B.abs_pad = abs_pad;
     const size_t max_open = (size_t)n / 2 + 2, max_nodes = 2 * (size_t)n + 2;
     std::vector<void *> temps;
     auto alloc = [&](size_t bytes, bool temp) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); if (temp) temps.push_back(p); return p; };
@@ -93,9 +97,9 @@ void free_device_tree(DeviceTree &t) {
     t.nodes = nullptr; t.order = nullptr; t.last = nullptr;
 }
 
-void gather_records(const void *d_in, void *d_out, const DeviceTree &t, uint32_t n, uint32_t elem_bytes, int mark_word_offset) {
+void gather_records(const void *d_in, void *d_out, const DeviceTree &t, uint32_t n, uint32_t elem_bytes, int mark_word_offset, bool or_into_word) {
     if (elem_bytes % 16) throw std::runtime_error("gather_records: record size must be a multiple of 16");
-    hipLaunchKernelGGL(gather16_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const float4 *)d_in, (float4 *)d_out, t.order, t.last, n, elem_bytes / 16, mark_word_offset);
+    hipLaunchKernelGGL(gather16_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, (const float4 *)d_in, (float4 *)d_out, t.order, t.last, n, elem_bytes / 16, mark_word_offset, or_into_word);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -71,6 +71,28 @@ def test_hw8_closest_hits_do_not_depend_on_the_tree(rt, monkeypatch, n):
     assert differing <= 2
 
 
+@pytest.mark.parametrize("case", ["sphere", "soup_with_ties"])
+def test_hw8_replay_walks_the_device_tree_and_keeps_the_reference_pixels(rt, monkeypatch, sphere_scene, case):
+    """Default scenes: figure order and exact walks from the host's replay of the reference's builder, walkers on the GPU-built tree
+    (every record carries its figure index).  Same pixels as walking the reference topology, ties included, and the oracle's."""
+    sd = sphere_scene if case == "sphere" else pin_cases.random_triangle_scene(n=600, seed=3)
+    w, h, spp = 80, 60, 6
+    scene = rt.Scene(sd)
+    info = scene.info()
+    assert info.bvh_on_device == 1
+    a, a8, st = scene.render(w, h, spp)
+    scene.close()
+    monkeypatch.setenv("RTAMD_HOST_BVH", "1")
+    host = rt.Scene(sd)
+    assert host.info().bvh_on_device == 0
+    b, b8, hst = host.render(w, h, spp)
+    host.close()
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a8, b8)
+    assert (st.closest_hit_queries, st.light_pdf_queries) == (hst.closest_hit_queries, hst.light_pdf_queries)
+    ref, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
+    assert np.array_equal(a, ref, equal_nan=True)
+
+
 def test_hw8_scene_with_lights_is_statistically_the_same(rt, sphere_scene):
     w, h, spp, k = 64, 48, 512, 8
     a, _, _ = rt.Scene(sphere_scene, build_flags=rt.RT_BUILD_DEVICE_BVH).render(w, h, spp, sample_streams=k)

@@ -358,7 +358,7 @@ def main():
                           "parallelism": f"pixel tiles {TILE}x{TILE} round-robin over {world} GPU(s)" + ((", gloo gather of u8 tiles (one-GPU rehearsal)" if rehearsal else ", RCCL gather of u8 tiles") if world > 1 else ""),
                           "bvh_nodes": int(info.n_bvh_nodes), "bvh_depth": int(info.bvh_depth), "light_bvh_depth": int(info.light_bvh_depth), "scene_prep_ms": round(info.prep_ms, 1), "scene_upload_ms": round(info.upload_ms, 1),
                           "scene_load_ms": round(t_load * 1e3, 1), "device_bytes": int(info.device_bytes)}
-        if world == 1:
+        if world == 1 and not args.no_cpu_baseline:  # a lean run (profilers use --no-cpu-baseline) launches nothing but the timed renders and the counting render
             # Untimed side measurement: the same scene with its tree built on the GPU (RT_BUILD_DEVICE_BVH).  Not the
             # headline: the figure order becomes the load order, so these frames follow the reference's estimator, not its pixels.
             try:

@@ -20,5 +20,9 @@ python3 tools/pmc_traffic.py $O/pmc_traffic synth_room_v1_1920x1080x256 $O/traff
 mkdir -p $O/pmc && cp -r $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_tcc $O/pmc/ 2>/dev/null || true
 python3 tools/summarize_rocprof.py $O/stats $O/${TAG}_final_rocprof.txt "bench.py --steps 2 --warmup 1 --no-cpu-baseline (1920x1080x256; persistent pipeline: two launches per frame)" > /dev/null
 python3 tools/summarize_rocprof.py $O/pmc $O/${TAG}_final_pmc.txt "FETCH_SIZE / WRITE_SIZE passes: bench.py --steps 1 --warmup 0 (full 256 spp, the counting side-render at 4 spp included); SQ / TCC passes: --spp 16" > /dev/null
+# BASELINE.json configs[2] (hw6 practice6_2, 1024x1024x256) under the same kernel-stats profiler
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_hw6 -- python3 tools/tuning/p6_probe.py --spp 256 "" > $O/stats_hw6_run.log 2>&1 || echo "hw6 stats pass failed"
+python3 tools/summarize_rocprof.py $O/stats_hw6 $O/${TAG}_hw6_config3_rocprof.txt "tools/tuning/p6_probe.py --spp 256 (hw6 practice6_2 1024x1024x256, persistent hw6 pipeline: two launches per frame, two renders)" > /dev/null || true
+rm -rf $O/stats_hw6
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_tcc $O/pmc $O/pmc_traffic
 ls -la $O

@@ -18,6 +18,7 @@
 #pragma once
 #include "rt_persistent.h"
 #include "rt_kernels_hw6.h"
+#include "rt_exact.h"
 
 namespace rtamd {
 namespace dev {
@@ -27,7 +28,7 @@ namespace dev {
 #define P6_NW (P6_MAX_PATHS / 32)
 #define P6_Q_SLOW 3                  // light sums with more than two hits: the complete per-lane light_pdf_sum6_fast
 #define P6_REC 56u                   // float4 per path record: 8 + 5 per frame x RT6_MAX_DEPTH + 8 for the hits of a light sum
-// record: r0 = o.xyz d.x | r1 = d.yz rng.x rng.saved | r2 = hit t, figure slot, inside, - | r3 = accum.xyz packed
+// record: r0 = o.xyz d.x | r1 = d.yz rng.x rng.saved | r2 = hit t, figure slot, inside, t of the runner-up | r3 = accum.xyz packed
 //         r4 = light-query origin xo.xyz, light sum (raw)  | r5 = pending emission.xyz, cosine pdf | r6 = pending colour.xyz, d.n
 //         r7 = number of lights the pdf's ray hit (when more than two), -, -, -
 //         frame f at r[8 + 5 f]: emission.xyz kind | mult.xyz inside | x.xyz ior | dn.xyz - | norma.xyz -
@@ -35,14 +36,17 @@ namespace dev {
 // packed: fp:4 | has_saved:16 | pending:32 | light_only:64 (the pending bounce's child is beyond the depth limit: no trace) | sample << 8
 #define P6_PENDING 32u
 #define P6_LIGHT_ONLY 64u
+#define P6_VERIFIED 128u             // the hit in r2 comes from the reference-exact walk: its index is a position in the reference's figure order
+#define P6_Q_XTRACE 4                // closest hits for the exact walk (rt_exact.h)
 // actions of p6_advance
 #define P6_TRACE 1
 #define P6_LIGHT 2
 #define P6_PARKED 8
+#define P6_EXACT 16                  // the hit does not stand as the reference's answer: exact walk first, nothing of the path was touched
 
 struct P6Shared {
     uint32_t stack[PT_WAVES][P6_STACK][64];
-    uint32_t need[4][P6_NW];
+    uint32_t need[5][P6_NW];
     uint32_t pending[P6_NW * 2];
     uint32_t groups[P6_MAX_PATHS / 64];
     uint32_t cost[P6_MAX_PATHS / 64];     // shader steps per local sub-tile in this launch: the load measure of the re-deal
@@ -72,6 +76,17 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
     int fp = (int)(packed & 15u);
     rng.has_saved = (packed & 16u) != 0;
     uint32_t sample = packed >> 8;
+    if (S.exact_boxes && !(packed & (P6_LIGHT_ONLY | P6_VERIFIED))) {
+        // the gate of rt_exact.h (pt_hit_stands), before anything of the path's state changes
+        const float4 g0 = r[0], g2 = r[2];
+        const uint32_t ghit = __float_as_uint(g2.y);
+        if (ghit != 0xFFFFFFFFu) {
+            const uint32_t ref_index = __float_as_uint(reinterpret_cast<const float4 *>(S.tris + ghit)[3].x);
+            const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)ref_index;
+            const float4 lo = bx[0], hi = bx[1];
+            if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), f3(g0.x, g0.y, g0.z), f3(g0.w, q1.x, q1.y), g2.x, g2.w - g2.x, S.box_c2, S.cull_k)) return P6_EXACT;
+        }
+    }
     F3 ret = f3(0.f, 0.f, 0.f);
     bool returning = false;
     if (packed & P6_PENDING) {
@@ -97,7 +112,7 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
         if (hit == 0xFFFFFFFFu) { ret = f3(S.bg); returning = true; }
         else {
             const bool inside = __float_as_uint(q2.z) != 0;
-            Tri6Regs T = load_tri6(S.tris + hit);
+            Tri6Regs T = load_tri6((packed & P6_VERIFIED) ? S.ref_tris + hit : S.tris + hit);
             const float4 *qm = reinterpret_cast<const float4 *>(S.materials + T.material);
             const float4 m0 = qm[0], m1 = qm[1];
             const F3 color = f3(m0.x, m0.y, m0.z), emission = f3(m1.x, m1.y, m1.z);
@@ -248,7 +263,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     int sp = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
-    float best_t = RT_T_MAX;
+    float best_t = RT_T_MAX, cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // look-behind and runner-up: rt_exact.h
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
@@ -269,7 +284,8 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = make_ray_inv(o, d);
-                    cur = 0; sp = 0; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; best_inside = false;
+                    h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2) : 0.f;
+                    cur = 0; sp = 0; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
                     active = true;
                 }
             }
@@ -285,14 +301,14 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
-                bool h0 = slab_test(lo0, hi0, ray, best_t, n0);
-                bool h1 = slab_test(lo1, hi1, ray, best_t, n1);
+                bool h0 = slab_test(lo0, hi0, ray, cull_t, n0);
+                bool h1 = slab_test(lo1, hi1, ray, cull_t, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) { bool swap = n1 < n0; stack[sp++][lane] = swap ? c0 : c1; cur = swap ? c1 : c0; }
                 else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) {
-                    p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), 0.f);
+                    p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
                     active = false; fin = l;
                 } else cur = stack[--sp][lane];
             }
@@ -305,15 +321,19 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     if (COUNT) n_tris++;
                     float t; bool inside;
                     // reference tie rule: smallest t, equal t -> lowest index in the reference's figure order
-                    if (tri6_test(T, o, d, t, inside) && (t < best_t || (t == best_t && T.ref_index < best_ref))) {
-                        best_t = t; best_inside = inside; hit = i; best_ref = T.ref_index;
+                    if (tri6_test(T, o, d, t, inside) && t <= cull_t) {
+                        if (t < best_t || (t == best_t && T.ref_index < best_ref)) {
+                            t2 = fminf(t2, best_t);
+                            best_t = t; best_inside = inside; hit = i; best_ref = T.ref_index;
+                            cull_t = S.exact_boxes ? t + fmaxf(S.cull_k * t, h_ray) : t;
+                        } else t2 = fminf(t2, t);
                     }
                     if (T.last) break;
                     i++;
                 }
             }
             if (sp == 0) {
-                p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), 0.f);
+                p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
                 active = false; fin = l;
             } else cur = stack[--sp][lane];
         }
@@ -326,7 +346,7 @@ template <bool COUNT>
 RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
     const int lane = threadIdx.x & 63;
-    bool active = false, refill_ok = true, many = false;
+    bool active = false, refill_ok = true, many = false, fragile = false; // fragile: a hit at a box boundary, the sum goes to the exact walk
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE, idx0 = 0, idx1 = 0;
     int sp = 0, k = 0;
     float term0 = 0.f, term1 = 0.f;
@@ -334,6 +354,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
+        if (fragile) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = 0xFFFFFFFFu; slow = l; return; }
         if (many) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k; slow = l; return; }
         const float v = k == 0 ? 0.f : (k == 1 ? term0 : term0 + term1);
         reinterpret_cast<float *>(p6_rec(W, slot) + 4)[3] = v;
@@ -360,7 +381,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     float4 q0 = r[0], q1 = r[1], q4 = r[4];
                     o = f3(q4.x, q4.y, q4.z); d = f3(q0.w, q1.x, q1.y);                        // the pdf's ray: x + eps*n towards the sampled direction
                     ray = make_ray_inv(o, d);
-                    cur = 0; sp = 0; k = 0; many = false; term0 = 0.f; term1 = 0.f;
+                    cur = 0; sp = 0; k = 0; many = false; fragile = false; term0 = 0.f; term1 = 0.f;
                     active = true;
                 }
             }
@@ -397,6 +418,12 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                         F3 yn = normalize(inside ? neg(T.n) : T.n);                          // primitives.cpp:31
                         F3 y = o + t * d;
                         const float term = T.point_prob * len2(o - y) / fabsf(dot(d, yn));    // distributions.h:116-118
+                        if (S.exact_boxes) { // is every box of the reference's light tree above this hit passed whatever the rounding? (rt_exact.h)
+                            const F3 pb = T.a + T.b, pc = T.a + T.c;
+                            const F3 blo = f3(fminf(T.a.x, fminf(pb.x, pc.x)), fminf(T.a.y, fminf(pb.y, pc.y)), fminf(T.a.z, fminf(pb.z, pc.z)));
+                            const F3 bhi = f3(fmaxf(T.a.x, fmaxf(pb.x, pc.x)), fmaxf(T.a.y, fmaxf(pb.y, pc.y)), fmaxf(T.a.z, fmaxf(pb.z, pc.z)));
+                            if (!pt_box_robust(blo, bhi, y, d, t, S.box_c2)) fragile = true;
+                        }
                         if (k == 0) { term0 = term; idx0 = T.ref_index; }
                         else if (k == 1) { term1 = term; idx1 = T.ref_index; }
                         else {
@@ -411,7 +438,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     i++;
                 }
             }
-            if (sp == 0 || k > RT6_MAX_LIGHT_HITS) finish();
+            if (sp == 0 || k > RT6_MAX_LIGHT_HITS || fragile) finish();
             else cur = stack[--sp][lane];
         }
     }
@@ -457,6 +484,77 @@ RT_DEV float p6_merge_hits(const SceneView6 &S, const float2 *h, int k, uint32_t
     return __uint_as_float(col[0][lane]);
 }
 
+// ---- exact role: BVH::intersect_ of hw6 (bvh.h, identical to hw8's) over the reference's own tree with the reference's box test, as an
+// iterative depth-first walk, left child first, one running best with strict '<' (ref_closest_hit of rt_exact.h with hw6's figures) ----
+RT_DEV void ref_closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack, float &best_t, bool &best_inside, uint32_t &hit) {
+    best_t = RT_T_MAX; best_inside = false; hit = 0xFFFFFFFFu;
+    if (S.n_tris == 0) return;
+    int sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        const RefNodeView n = load_ref_node(S.ref_nodes + cur);
+        float tb; bool inside;
+        if (ref_box_test(n.mn, n.mx, o, d, tb, inside) && !(hit != 0xFFFFFFFFu && best_t < tb && !inside)) {
+            if (n.left == 0) {
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    const Tri6Regs T = load_tri6(S.ref_tris + i);
+                    float t; bool in;
+                    if (tri6_test(T, o, d, t, in) && (hit == 0xFFFFFFFFu || t < best_t)) { best_t = t; best_inside = in; hit = i; }
+                }
+            } else if (sp < RT6_STACK_SIZE) { stack[sp++] = n.right; cur = n.left; continue; }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+
+// FiguresMix::getTotalPdf of hw6 (distributions.h:212-256) over the reference's own light tree with the reference's box test and its
+// association of the additions (ref_light_pdf_sum of rt_exact.h with hw6's term).  The tree is degenerate (85 levels on practice6_2):
+// thousands of box tests per query, which is why only light sums with a hit at a box boundary come here.
+RT_DEV float ref_light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
+    int sp = 0;
+    unsigned long long mask_lo = 0, mask_hi = 0;
+    uint32_t cur = 0;
+    bool descending = true;
+    float v = 0.f;
+    if (S.n_lights == 0) return 0.f;
+    for (;;) {
+        if (descending) {
+            const RefNodeView n = load_ref_node(S.ref_light_nodes + cur);
+            float tb; bool inside;
+            if (!ref_box_test(n.mn, n.mx, x, d, tb, inside)) { v = 0.f; descending = false; }
+            else if (n.left == 0) {
+                float result = 0.f;
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    const Tri6Regs T = load_tri6(S.lights + i);
+                    float t; bool in; float term = 0.f;
+                    if (tri6_test(T, x, d, t, in)) {
+                        const F3 yn = normalize(in ? neg(T.n) : T.n);
+                        const F3 y = x + t * d;
+                        term = T.point_prob * len2(x - y) / fabsf(dot(d, yn));
+                    }
+                    result += term;
+                }
+                v = result; descending = false;
+            } else if (sp < RT6_STACK_SIZE) {
+                if (sp < 64) mask_lo &= ~(1ull << sp); else mask_hi &= ~(1ull << (sp - 64));
+                stack[sp++] = n.right; cur = n.left;
+            } else { v = 0.f; descending = false; }
+        } else {
+            if (sp == 0) break;
+            --sp;
+            const uint32_t f = stack[sp];
+            const bool is_add = sp < 64 ? ((mask_lo >> sp) & 1ull) != 0 : ((mask_hi >> (sp - 64)) & 1ull) != 0;
+            if (is_add) v = __uint_as_float(f) + v;
+            else {
+                if (sp < 64) mask_lo |= 1ull << sp; else mask_hi |= 1ull << (sp - 64);
+                stack[sp++] = __float_as_uint(v); cur = f; descending = true;
+            }
+        }
+    }
+    return v;
+}
+
 // ---- the kernel (scheduler of rt_persistent.h) ------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S, RenderView R, W6View W, PtParams P) {
@@ -471,7 +569,7 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
     wv.nw = n_local_groups * 2u;
     if (wv.n_local == 0u) return;
     for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
-    for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; }
+    for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
     for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
     for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
     if (tid < 16u) sh.cnt[tid] = 0;
@@ -518,7 +616,7 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
 
     uint32_t(*stack)[64] = sh.stack[wave];
     const int shade_thr = P.shade_thr0 + (int)wave * P.shade_thr_step;
-    uint32_t n_closest = 0, n_light = 0, n_slow = 0;
+    uint32_t n_closest = 0, n_light = 0, n_slow = 0, n_exact = 0, n_xlight = 0;
     unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t idle_spins = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -540,7 +638,11 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
                 float4 *r = p6_rec(W, pt_slot(sh, got));
                 const int k = (int)reinterpret_cast<const uint32_t *>(r + 7)[0];
                 float v;
-                if (k > RT6_MAX_LIGHT_HITS) {
+                if (k < 0) { // 0xFFFFFFFF: a hit at a box boundary
+                    const float4 q0 = r[0], q1 = r[1], q4 = r[4];
+                    v = ref_light_pdf_sum6(S, f3(q4.x, q4.y, q4.z), f3(q0.w, q1.x, q1.y), deep_stack);
+                    n_xlight++;
+                } else if (k > RT6_MAX_LIGHT_HITS) {
                     const float4 q0 = r[0], q1 = r[1], q4 = r[4];
                     v = light_pdf_sum6(S, f3(q4.x, q4.y, q4.z), f3(q0.w, q1.x, q1.y), deep_stack);
                 } else {
@@ -555,17 +657,39 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
             clock_role(3);
             continue;
         }
+        if (pt_count(&sh.cnt[P6_Q_XTRACE]) > 0) {
+            // hits that do not stand as the reference's answer (~1e-5 of them): the reference's own walk, one lane per query
+            uint32_t xstack[RT6_STACK_SIZE];
+            const uint32_t got = pt_pop(sh.need[P6_Q_XTRACE], &sh.cnt[P6_Q_XTRACE], wv.nw, wv.cur[P6_Q_XTRACE], true);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (got != PT_NONE) {
+                float4 *r = p6_rec(W, pt_slot(sh, got));
+                const float4 q0 = r[0], q1 = r[1];
+                float bt; bool bin; uint32_t bhit;
+                ref_closest_hit6(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, bt, bin, bhit);
+                r[2] = make_float4(bt, __uint_as_float(bhit), __uint_as_float(bin ? 1u : 0u), 0.f);
+                float *pk = reinterpret_cast<float *>(r + 3) + 3;
+                *pk = __uint_as_float(__float_as_uint(*pk) | P6_VERIFIED);
+            }
+            n_exact += __popcll(__ballot(got != PT_NONE));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
+            idle_spins = 0;
+            clock_role(3);
+            continue;
+        }
         if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
             const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             int todo = 0;
             if (got != PT_NONE) todo = p6_advance(S, R, W, pt_slot(sh, got));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            const bool tr = got != PT_NONE && (todo & P6_TRACE), li = got != PT_NONE && (todo & P6_LIGHT);
+            pt_push(sh, P6_Q_XTRACE, got, got != PT_NONE && todo == P6_EXACT);
+            const bool tr = got != PT_NONE && todo != P6_EXACT && (todo & P6_TRACE), li = got != PT_NONE && todo != P6_EXACT && (todo & P6_LIGHT);
             if (tr || li) atomicOr(&sh.pending[got >> 4], ((tr ? PT_BIT_T : 0u) | (li ? PT_BIT_L : 0u)) << ((got & 15u) * 2u));
             pt_push(sh, PT_Q_TRACE, got, tr);
             pt_push(sh, PT_Q_LIGHT, got, li);
-            if (got != PT_NONE) atomicAdd(&sh.cost[got >> 6], 1u);
+            if (got != PT_NONE && todo != P6_EXACT) atomicAdd(&sh.cost[got >> 6], 1u);
             const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == P6_PARKED));
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;
@@ -604,6 +728,8 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
         if (n_closest) atomicAdd(&P.counters[0], (unsigned long long)n_closest);
         if (n_light) atomicAdd(&P.counters[1], (unsigned long long)n_light);
         if (n_slow) atomicAdd(&P.counters[13], (unsigned long long)n_slow);
+        if (n_exact) atomicAdd(&P.counters[12], (unsigned long long)n_exact);
+        if (n_xlight) atomicAdd(&P.counters[11], (unsigned long long)n_xlight);
     }
     if (COUNT && P.counters) {
         atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris);

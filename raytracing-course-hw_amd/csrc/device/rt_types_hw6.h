@@ -30,6 +30,13 @@ struct SceneView6 {
     const Tri6 *fast_lights;         // the light records in that tree's leaf order (ref_index = position in the reference's light order)
     const uint32_t *light_ref;       // the reference light tree without boxes: 4 words {left, right, first, last} per node (left = 0: leaf)
     const uint16_t *light_sep;       // range-minimum table of the separation depths of neighbouring lights in the reference light tree (scene_prep.h)
+    // Reference-exact closest hits (device/rt_exact.h, as for hw8): the reference's own scene tree with its unpadded boxes, the figure
+    // records and their boxes (lo.xyz, -, hi.xyz, -) in the reference's figure order
+    const GpuRefNode *ref_nodes, *ref_light_nodes;
+    const Tri6 *ref_tris;
+    const float *tri_box;
+    float box_c2, cull_k;            // 2^-20 x the largest |coordinate|; the walkers' relative look-behind
+    uint32_t exact_boxes;
     const GpuMaterial6 *materials;
     uint32_t n_tris, n_lights, n_components;
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];

@@ -478,13 +478,17 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on
     //    (hw6/src/include/bvh.h:61-63); the resulting permutation is what introsort does with all-equal keys.
     out.figure_order.resize(n);
     for (uint32_t i = 0; i < n; i++) out.figure_order[i] = i;
-    {
-        RefBuilder ref(zero_keys, boxes, out.figure_order);
-        ref.run(n);
-        out.ref_bvh_depth = ref.depth;
-    }
+    RefBuilder ref(zero_keys, boxes, out.figure_order);
+    ref.run(n);
+    out.ref_bvh_depth = ref.depth;
+    encode_ref_tree(ref.nodes, out.ref_nodes);
     std::vector<uint32_t> ref_pos(n);
     for (uint32_t i = 0; i < n; i++) ref_pos[out.figure_order[i]] = i;
+    // the reference leaf box of every triangle (LOAD order): what the walkers' own tree is built over (see PreparedScene::walk_box)
+    std::vector<Box3> leaf_box = boxes;
+    for (const RefNode &rn : ref.nodes)
+        if (rn.left == 0)
+            for (uint32_t i = rn.first; i < rn.last; i++) leaf_box[out.figure_order[i]] = rn.box;
     // 2. light order + light tree (reference topology: it fixes the order of the float additions)
     auto emissive = [&](uint32_t tri) {
         const rt_material &m = d.materials[d.material_index[tri]];
@@ -498,6 +502,7 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on
     std::vector<uint32_t> light_leaf_last, scene_leaf_last;
     out.box_pad = scene_abs_pad(boxes, d.camera);
     encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last, out.box_pad);
+    encode_ref_tree(light_builder.nodes, out.ref_light_nodes);
     out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
     // 3. own scene tree: the same full-sweep SAH builder keyed on the data3 vertex (as hw8 does) -- or, when the caller builds the
     //    tree on the GPU (device/rt_bvh_build.h), the records stay in LOAD order and the boxes go along
@@ -506,7 +511,7 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on
     if (tree_on_device) {
         out.boxes8.assign((size_t)n * 8, 0.f);
         for (uint32_t i = 0; i < n; i++)
-            for (int k = 0; k < 3; k++) { out.boxes8[8 * (size_t)i + k] = boxes[i].lo[k]; out.boxes8[8 * (size_t)i + 4 + k] = boxes[i].hi[k]; }
+            for (int k = 0; k < 3; k++) { out.boxes8[8 * (size_t)i + k] = leaf_box[i].lo[k]; out.boxes8[8 * (size_t)i + 4 + k] = leaf_box[i].hi[k]; }
     } else {
         RefBuilder mine(keys, boxes, my_order);
         mine.run(n);
@@ -529,6 +534,14 @@ void prepare_scene_hw6(const rt_scene_desc &d, PreparedScene6 &out, bool tree_on
     out.tris.resize(n);
     for (uint32_t i = 0; i < n; i++) { out.tris[i] = make(my_order[i]); out.tris[i].ref_index = ref_pos[my_order[i]]; }
     for (uint32_t i : scene_leaf_last) out.tris[i].last = 1;
+    out.ref_tris.resize(n);
+    out.tri_box.assign((size_t)(n ? n : 1) * 8, 0.f);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t src = out.figure_order[i];
+        out.ref_tris[i] = make(src); out.ref_tris[i].ref_index = i;
+        for (int k = 0; k < 3; k++) { out.tri_box[8 * (size_t)i + k] = boxes[src].lo[k]; out.tri_box[8 * (size_t)i + 4 + k] = boxes[src].hi[k]; }
+    }
+    out.box_c2 = out.box_pad * 0.25f; // 2^-20 x the largest |coordinate|
     out.lights.resize(n_lights);
     for (uint32_t i = 0; i < n_lights; i++) { out.lights[i] = make(out.light_order[i]); out.lights[i].ref_index = i; }
     for (uint32_t i : light_leaf_last) out.lights[i].last = 1;

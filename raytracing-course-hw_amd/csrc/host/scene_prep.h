@@ -51,7 +51,11 @@ struct PreparedScene6 {
     uint32_t fast_light_bvh_depth = 0;
     std::vector<uint32_t> light_ref; // 4 words per reference light-tree node: left, right, first, last
     std::vector<uint16_t> light_sep; // as PreparedScene::light_sep, over the reference light tree of hw6
-    std::vector<float> boxes8;       // tree_on_device only
+    std::vector<GpuRefNode> ref_nodes, ref_light_nodes; // the reference's own trees with their unpadded boxes, for the exact walks
+    std::vector<Tri6> ref_tris;        // figure records in the reference's figure order (ref_index = position)
+    std::vector<float> tri_box;        // their own boxes, 8 floats each
+    float box_c2 = 0.f;
+    std::vector<float> boxes8;       // tree_on_device only: per triangle (LOAD order) the box of its reference leaf
     float box_pad = 0.f;             // as PreparedScene::box_pad
     uint32_t light_sep_levels = 0;
     std::vector<GpuMaterial6> materials;

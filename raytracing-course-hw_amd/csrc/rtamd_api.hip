@@ -270,6 +270,13 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             V.fast_light_nodes = keep(upload(P6.fast_light_nodes, bytes));
             V.fast_lights = keep(upload(P6.fast_lights, bytes));
             V.light_ref = keep(upload(P6.light_ref, bytes));
+            V.ref_nodes = keep(upload(P6.ref_nodes, bytes));
+            V.ref_light_nodes = keep(upload(P6.ref_light_nodes, bytes));
+            V.ref_tris = keep(upload(P6.ref_tris, bytes));
+            V.tri_box = keep(upload(P6.tri_box, bytes));
+            V.box_c2 = P6.box_c2;
+            V.cull_k = getenv("RTAMD_CULL_K") ? (float)atof(getenv("RTAMD_CULL_K")) : 0.0078125f;
+            V.exact_boxes = getenv("RTAMD_NO_EXACT_BOXES") ? 0u : 1u;
             V.light_sep = keep(upload(P6.light_sep, bytes));
             V.materials = keep(upload(P6.materials, bytes));
             V.n_tris = desc->n_triangles;
@@ -1020,8 +1027,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipStreamSynchronize(stream)); // render is synchronous on return
         use_persistent = use_persistent && use_wavefront && blocks;
         if (use_persistent6 && getenv("RTAMD_DEBUG_COUNTERS")) {
-            fprintf(stderr, "[rtamd] persistent hw6 pipeline: %u launches; re-deal %.2f ms on the host (slowest workgroup / mean under the round-robin deal: %.3f); light sums through the slow role %llu of %llu\n",
-                    scene->pt_launches, scene->pt_rebalance_ms, scene->pt_imbalance, h_cnt[13], h_cnt[1]);
+            fprintf(stderr, "[rtamd] persistent hw6 pipeline: %u launches; re-deal %.2f ms on the host (slowest workgroup / mean under the round-robin deal: %.3f); light sums through the slow role %llu of %llu; exact closest-hit walks %llu of %llu, exact light sums %llu\n",
+                    scene->pt_launches, scene->pt_rebalance_ms, scene->pt_imbalance, h_cnt[13], h_cnt[1], h_cnt[12], h_cnt[0], h_cnt[11]);
             if (count) {
                 const double tt = (double)(h_cnt[16] + h_cnt[17] + h_cnt[18] + h_cnt[19] + h_cnt[20]);
                 fprintf(stderr, "[rtamd] persistent hw6 kernel, wave time by role: closest-hit walks %.1f %%, light walks %.1f %%, shading %.1f %%, slow light sums %.1f %%, idle %.1f %%\n",

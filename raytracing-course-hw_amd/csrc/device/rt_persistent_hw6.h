@@ -354,7 +354,12 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
-        if (fragile) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = 0xFFFFFFFFu; slow = l; return; }
+        if (fragile) { // the hits go along (also when there are fewer than three), the slow role adds them with the reference's box tests
+            float2 *h = reinterpret_cast<float2 *>(p6_rec(W, slot) + 48);
+            if (k >= 1 && k <= 2) h[0] = make_float2(__uint_as_float(idx0), term0);
+            if (k == 2) h[1] = make_float2(__uint_as_float(idx1), term1);
+            reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k | 0x80000000u; slow = l; return;
+        }
         if (many) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k; slow = l; return; }
         const float v = k == 0 ? 0.f : (k == 1 ? term0 : term0 + term1);
         reinterpret_cast<float *>(p6_rec(W, slot) + 4)[3] = v;
@@ -438,7 +443,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     i++;
                 }
             }
-            if (sp == 0 || k > RT6_MAX_LIGHT_HITS || fragile) finish();
+            if (sp == 0 || k > RT6_MAX_LIGHT_HITS) finish();
             else cur = stack[--sp][lane];
         }
     }
@@ -505,6 +510,119 @@ RT_DEV void ref_closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack, f
         }
         if (sp == 0) break;
         cur = stack[--sp];
+    }
+}
+
+// The reference's trees are degenerate here (built on a constant sort key: 59 and 85 levels, tens of thousands of box tests per query),
+// so the exact walks do not walk them blindly.  A subtree without a hit of the ray is a no-op in the reference's recursion (it returns
+// "nothing" / adds 0 and leaves curBest alone), so it is enough to (1) find every figure the ray hits with the library's own tree,
+// (2) sort those by their position in the reference's order, (3) run the reference's recursion only along the root-to-leaf paths that
+// lead to them -- every node on such a path gets the reference's box test and pruning rule, every hit its triangle test again, in
+// the reference's order.  A few hundred box tests instead of tens of thousands; more hits than P6_XHITS fall back to the blind walk.
+#define P6_XHITS 48
+RT_DEV bool p6_all_hits(const SceneView6 &S, F3 o, F3 d, uint32_t *stack, uint32_t *hits, int &k) { // unsorted reference indices; false = too many
+    RayInv ray = make_ray_inv(o, d);
+    int sp = 0; k = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        if (cur & RT_LEAF_BIT) {
+            if (cur != RT_EMPTY_LEAF) {
+                uint32_t i = cur & ~RT_LEAF_BIT;
+                for (;;) {
+                    const Tri6Regs T = load_tri6(S.tris + i);
+                    float t; bool inside;
+                    if (tri6_test(T, o, d, t, inside)) { if (k == P6_XHITS) return false; hits[k++] = T.ref_index; }
+                    if (T.last) break;
+                    i++;
+                }
+            }
+            if (sp == 0) return true;
+            cur = stack[--sp];
+            continue;
+        }
+        const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
+        const float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
+        float n0, n1;
+        const bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0), h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
+        const uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
+        if (h0 & h1) { stack[sp++] = c1; cur = c0; }
+        else if (h0) cur = c0;
+        else if (h1) cur = c1;
+        else { if (sp == 0) return true; cur = stack[--sp]; }
+    }
+}
+RT_DEV void p6_sort_hits(uint32_t *hits, int k) {
+    for (int i = 1; i < k; i++) { const uint32_t v = hits[i]; int j = i - 1; while (j >= 0 && hits[j] > v) { hits[j + 1] = hits[j]; j--; } hits[j + 1] = v; }
+}
+// BVH::intersect_ restricted to the paths towards hits[lo..hi): stack words = node | lo << 19 | hi << 25 (node < 2^19, k <= 63)
+RT_DEV void ref_closest_hit6_along(const SceneView6 &S, F3 o, F3 d, const uint32_t *hits, int k, uint32_t *stack, float &best_t, bool &best_inside, uint32_t &hit) {
+    best_t = RT_T_MAX; best_inside = false; hit = 0xFFFFFFFFu;
+    if (k == 0) return;
+    int sp = 0;
+    uint32_t node = 0; int lo = 0, hi = k;
+    for (;;) {
+        const RefNodeView n = load_ref_node(S.ref_nodes + node);
+        float tb; bool inside;
+        bool descend = false;
+        if (ref_box_test(n.mn, n.mx, o, d, tb, inside) && !(hit != 0xFFFFFFFFu && best_t < tb && !inside)) {
+            if (n.left == 0) {
+                for (int j = lo; j < hi; j++) {
+                    const Tri6Regs T = load_tri6(S.ref_tris + hits[j]);
+                    float t; bool in;
+                    if (tri6_test(T, o, d, t, in) && (hit == 0xFFFFFFFFu || t < best_t)) { best_t = t; best_inside = in; hit = hits[j]; }
+                }
+            } else {
+                const uint32_t right_first = S.ref_nodes[n.right].first;
+                int m = lo;
+                while (m < hi && hits[m] < right_first) m++;
+                if (m > lo) { // the left child leads to hits: go there, the right one (if it does too) waits
+                    if (m < hi) stack[sp++] = n.right | ((uint32_t)m << 19) | ((uint32_t)hi << 25);
+                    node = n.left; hi = m; descend = true;
+                } else { node = n.right; descend = true; }
+            }
+        }
+        if (descend) continue;
+        if (sp == 0) return;
+        const uint32_t w = stack[--sp];
+        node = w & 0x7FFFFu; lo = (int)((w >> 19) & 63u); hi = (int)(w >> 25);
+    }
+}
+// FiguresMix::getTotalPdf restricted to the paths towards the hit lights (sorted by index): the addition tree of light_sum6_associate
+// with the reference's box test at every node on the way (a failed box contributes 0 whatever lies below it).
+RT_DEV float ref_light_pdf_sum6_along(const SceneView6 &S, F3 x, F3 d, uint32_t *hit_idx, float *hit_term, int k) {
+    if (k == 0) return 0.f;
+    for (int i = 1; i < k; i++) {
+        uint32_t id = hit_idx[i]; float tm = hit_term[i];
+        int j = i - 1;
+        while (j >= 0 && hit_idx[j] > id) { hit_idx[j + 1] = hit_idx[j]; hit_term[j + 1] = hit_term[j]; j--; }
+        hit_idx[j + 1] = id; hit_term[j + 1] = tm;
+    }
+    uint32_t f_node[RT6_MAX_LIGHT_HITS]; int f_lo[RT6_MAX_LIGHT_HITS], f_hi[RT6_MAX_LIGHT_HITS]; float f_val[RT6_MAX_LIGHT_HITS]; uint32_t f_add = 0;
+    int fsp = 0;
+    uint32_t node = 0; int lo = 0, hi = k;
+    float v = 0.f;
+    for (;;) {
+        for (;;) { // total of hits [lo, hi) under `node`
+            const RefNodeView n = load_ref_node(S.ref_light_nodes + node);
+            float tb; bool inside;
+            if (!ref_box_test(n.mn, n.mx, x, d, tb, inside)) { v = 0.f; break; }
+            if (n.left == 0) { v = 0.f; for (int j = lo; j < hi; j++) v += hit_term[j]; break; }
+            const uint32_t right_first = S.ref_light_nodes[n.right].first;
+            int m = lo;
+            while (m < hi && hit_idx[m] < right_first) m++;
+            if (m == lo) { node = n.right; continue; }
+            if (m == hi) { node = n.left; continue; }
+            f_node[fsp] = n.right; f_lo[fsp] = m; f_hi[fsp] = hi; f_add &= ~(1u << fsp); fsp++;
+            node = n.left; hi = m;
+        }
+        for (;;) {
+            if (fsp == 0) return v;
+            fsp--;
+            if ((f_add >> fsp) & 1u) { v = f_val[fsp] + v; continue; }
+            node = f_node[fsp]; lo = f_lo[fsp]; hi = f_hi[fsp];
+            f_val[fsp] = v; f_add |= 1u << fsp; fsp++;
+            break;
+        }
     }
 }
 
@@ -636,11 +754,19 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (got != PT_NONE) {
                 float4 *r = p6_rec(W, pt_slot(sh, got));
-                const int k = (int)reinterpret_cast<const uint32_t *>(r + 7)[0];
+                const uint32_t kw = reinterpret_cast<const uint32_t *>(r + 7)[0];
+                const int k = (int)(kw & 0x7FFFFFFFu);
                 float v;
-                if (k < 0) { // 0xFFFFFFFF: a hit at a box boundary
+                if (kw >> 31) { // a hit at a box boundary: the reference's own box tests decide
                     const float4 q0 = r[0], q1 = r[1], q4 = r[4];
-                    v = ref_light_pdf_sum6(S, f3(q4.x, q4.y, q4.z), f3(q0.w, q1.x, q1.y), deep_stack);
+                    const F3 lx = f3(q4.x, q4.y, q4.z), ld = f3(q0.w, q1.x, q1.y);
+                    if (k > RT6_MAX_LIGHT_HITS) v = ref_light_pdf_sum6(S, lx, ld, deep_stack);
+                    else {
+                        uint32_t hit_idx[RT6_MAX_LIGHT_HITS]; float hit_term[RT6_MAX_LIGHT_HITS];
+                        const float2 *h = reinterpret_cast<const float2 *>(r + 48);
+                        for (int i = 0; i < k; i++) { const float2 e = h[i]; hit_idx[i] = __float_as_uint(e.x); hit_term[i] = e.y; }
+                        v = ref_light_pdf_sum6_along(S, lx, ld, hit_idx, hit_term, k);
+                    }
                     n_xlight++;
                 } else if (k > RT6_MAX_LIGHT_HITS) {
                     const float4 q0 = r[0], q1 = r[1], q4 = r[4];
@@ -666,7 +792,10 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
                 float4 *r = p6_rec(W, pt_slot(sh, got));
                 const float4 q0 = r[0], q1 = r[1];
                 float bt; bool bin; uint32_t bhit;
-                ref_closest_hit6(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, bt, bin, bhit);
+                uint32_t xhits[P6_XHITS]; int xk;
+                const F3 xo = f3(q0.x, q0.y, q0.z), xd = f3(q0.w, q1.x, q1.y);
+                if (S.n_tris < (1u << 18) /* the path stack packs node numbers into 19 bits */ && p6_all_hits(S, xo, xd, xstack, xhits, xk)) { p6_sort_hits(xhits, xk); ref_closest_hit6_along(S, xo, xd, xhits, xk, xstack, bt, bin, bhit); }
+                else ref_closest_hit6(S, xo, xd, xstack, bt, bin, bhit);
                 r[2] = make_float4(bt, __uint_as_float(bhit), __uint_as_float(bin ? 1u : 0u), 0.f);
                 float *pk = reinterpret_cast<float *>(r + 3) + 3;
                 *pk = __uint_as_float(__float_as_uint(*pk) | P6_VERIFIED);

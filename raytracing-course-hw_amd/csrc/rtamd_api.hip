@@ -1104,7 +1104,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 double sum = 0;
                 for (uint32_t pp = 0; time_trace && pp < scene->pt_launches; pp++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * pp], scene->ev_pool[2 * pp + 1])); sum += e; }
                 stats->dominant_kernel_ms = time_trace ? sum : ms; stats->dominant_kernel_launches = scene->pt_launches;
-                stats->exact_closest_hits = h_cnt[12]; stats->exact_light_sums = h_cnt[13];
+                stats->exact_closest_hits = h_cnt[12]; stats->exact_light_sums = use_persistent6 ? h_cnt[11] : h_cnt[13];
             } else if (use_wavefront && blocks && time_trace) {
                 stats->exact_closest_hits = h_cnt[12]; stats->exact_light_sums = h_cnt[13]; // counting renders only
                 size_t rounds = wavefront_rounds(V8, R);

@@ -80,3 +80,20 @@ def test_config3_practice6_2_1024x1024x256_crop(rt):
         rmse, bad = _cmp("config3 crop vs the reference itself", rgb[y0:y0 + 16, x0:x0 + 16], rref, rgb8[y0:y0 + 16, x0:x0 + 16], rref8)
         assert rmse < RMSE_TOL
     scene.close()
+
+
+def test_full_size_pixels_that_need_the_references_own_box_decisions(rt):
+    """Found by tools/tuning/hw6_fullframe_check.py: seven pixels of a 384x384 crop of the 1024x1024 frame (16 spp) were off by up to 0.33
+    before the exactness gate of DESIGN.md 3 was ported to hw6 (hits at a box boundary of the reference's degenerate trees, its pruning
+    against hits in a box face).  Here: an 8x8 block around each of them against the oracle, bit for bit."""
+    sd = pin_cases.load_hw6("practice6_2")
+    scene = rt.Scene(sd)
+    w = h = 1024
+    rgb, _, st = scene.render(w, h, 16, integrator=rt.RT_INTEGRATOR_HW6, want_rgb8=False)
+    scene.close()
+    assert st.exact_closest_hits > 0 and st.exact_light_sums > 0       # the exact roles ran (about 1e-4 of the queries)
+    orc = oracle_lib.Hw6Oracle(sd)
+    for (x, y) in [(510, 375), (521, 381), (551, 469), (673, 469), (565, 513), (476, 603), (451, 609)]:
+        x0, y0 = x - 4, y - 4
+        ref, _, _ = orc.render(w, h, 16, rect=(x0, y0, 8, 8))
+        assert np.array_equal(rgb[y0:y0 + 8, x0:x0 + 8], ref), f"block at ({x0},{y0}) differs from the oracle"

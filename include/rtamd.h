@@ -120,7 +120,7 @@ typedef struct rt_camera {
  * hw8/src/sceneio.cpp:289. */
 typedef struct rt_scene_desc {
     uint32_t struct_size;            /* = sizeof(rt_scene_desc) */
-    uint32_t n_triangles;
+    uint32_t n_triangles;            /* hw7 / hw8 scenes: at most 2^24 - 2 (24 bits of figure index in a hit record) */
     const float *positions;          /* n_triangles * 9  */
     const float *texcoords;          /* n_triangles * 6  (may be NULL for HW6) */
     const float *normals;            /* n_triangles * 9  (may be NULL for HW6) */

@@ -109,3 +109,29 @@ def test_hw8_scene_with_lights_is_statistically_the_same(rt, sphere_scene):
 def test_unknown_build_flags_are_refused(rt, sphere_scene):
     with pytest.raises(Exception):
         rt.Scene(sphere_scene, build_flags=0x80)
+
+
+def test_full_frames_do_not_depend_on_the_walkers_tree(rt, monkeypatch, tmp_path):
+    """The detector that found the decisions of DESIGN.md 3 (b) and (c): render the whole headline frame on the GPU-built tree and on the
+    reference topology; any triangle one walk sees and the other does not, and any hit only one of them sends to the exact walk,
+    shows up as a differing pixel (15-21 of them at 32 spp before the runner-up window and the look-behind).  Same for hw6."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_synth_room
+    path, _ = gen_synth_room.generate(str(tmp_path), 64, 50, 43)
+    cases = [("hw8 headline scene", rt.load_gltf(path), rt.RT_INTEGRATOR_HW8, 1920, 1080, 16),
+             ("hw6 practice6_2", pin_cases.load_hw6("practice6_2"), rt.RT_INTEGRATOR_HW6, 1024, 1024, 8)]
+    for name, sd, integrator, w, h, spp in cases:
+        frames = []
+        for host in (False, True):
+            if host: monkeypatch.setenv("RTAMD_HOST_BVH", "1")
+            else: monkeypatch.delenv("RTAMD_HOST_BVH", raising=False)
+            scene = rt.Scene(sd)
+            assert scene.info().bvh_on_device == (0 if host else 1)
+            rgb, _, st = scene.render(w, h, spp, integrator=integrator, want_rgb8=False)
+            frames.append(rgb)
+            scene.close()
+        monkeypatch.delenv("RTAMD_HOST_BVH", raising=False)
+        differing = int(np.any(frames[0] != frames[1], axis=2).sum())
+        print(f"{name} {w}x{h}x{spp}: {differing} pixels differ between the two trees")
+        assert differing == 0

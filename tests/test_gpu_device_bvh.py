@@ -135,3 +135,38 @@ def test_full_frames_do_not_depend_on_the_walkers_tree(rt, monkeypatch, tmp_path
         differing = int(np.any(frames[0] != frames[1], axis=2).sum())
         print(f"{name} {w}x{h}x{spp}: {differing} pixels differ between the two trees")
         assert differing == 0
+
+
+@pytest.mark.parametrize("case", ["identical", "coplanar", "degenerate", "far_from_origin"])
+def test_builder_edge_cases_render_like_the_reference_topology(rt, monkeypatch, case):
+    """Inputs that stress the GPU builder: 120 identical triangles (no split plane separates them: one large leaf), a coplanar sheet (flat
+    boxes on one axis, zero centroid extent there), zero-area triangles, and a scene far from the origin (absolute padding and c2 scale
+    with the largest coordinate).  Replay mode with exact decisions: the frame must equal the one walked on the reference topology."""
+    sd = pin_cases.random_triangle_scene(n=400, seed=21)
+    rng = np.random.default_rng(5)
+    if case == "identical":
+        sd.positions[100:220] = sd.positions[100]
+    elif case == "coplanar":
+        sd.positions.reshape(-1, 3, 3)[:300, :, 1] = -1.5           # 300 triangles in the plane y = -1.5
+    elif case == "degenerate":
+        sd.positions.reshape(-1, 3, 3)[50:90, 1] = sd.positions.reshape(-1, 3, 3)[50:90, 0]   # two equal vertices
+        sd.positions.reshape(-1, 3, 3)[90:110] = sd.positions.reshape(-1, 3, 3)[90:110, :1]  # a point
+    else:
+        sd.positions.reshape(-1, 3, 3)[:] += np.array([900.0, -400.0, 250.0], np.float32)
+        sd.camera.position = (900.0, -400.0, 256.0)
+    sd._build_desc()
+    w, h, spp = 80, 60, 6
+    frames = []
+    for host in (False, True):
+        if host: monkeypatch.setenv("RTAMD_HOST_BVH", "1")
+        else: monkeypatch.delenv("RTAMD_HOST_BVH", raising=False)
+        scene = rt.Scene(sd)
+        info = scene.info()
+        assert info.bvh_on_device == (0 if host else 1) and (host or info.bvh_depth <= 28)
+        rgb, rgb8, st = scene.render(w, h, spp)
+        frames.append((rgb, rgb8))
+        scene.close()
+    monkeypatch.delenv("RTAMD_HOST_BVH", raising=False)
+    assert np.array_equal(frames[0][0], frames[1][0], equal_nan=True) and np.array_equal(frames[0][1], frames[1][1])
+    ref, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
+    assert np.array_equal(frames[0][0], ref, equal_nan=True)

@@ -619,6 +619,23 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
         }
 }
 
+// Sample counts at which the launches of a persistent render stop (the last one = the frame).  Two phases: 1/16 of the samples under the
+// round-robin deal, the rest after the re-deal.  RTAMD_PT_PHASES=3 deals the last quarter of the remaining samples once more, from the
+// costs measured over the long middle phase — measured: no gain (hw6 practice6_2 191.7 vs 193.6 Msamples/s, headline 284.2 vs 284.6):
+// what remains of the spread of the workgroups' exit times after one re-deal is not the amount of work but the serial samples of the
+// slowest pixels.
+static std::vector<int> phase_stops(bool rebalance, int phase0, int samples, int default_phases) {
+    std::vector<int> stops;
+    if (rebalance) {
+        stops.push_back(phase0);
+        const int want = getenv("RTAMD_PT_PHASES") ? atoi(getenv("RTAMD_PT_PHASES")) : default_phases;
+        const int mid = phase0 + (samples - phase0) * 3 / 4;
+        if (want >= 3 && samples >= 64 && mid > phase0 && mid < samples) stops.push_back(mid);
+    }
+    stops.push_back(samples);
+    return stops;
+}
+
 // Between the two phases of a persistent render: read the hits every workgroup shaded per 8x8 sub-tile in the first phase and deal the
 // sub-tiles again, longest processing time first onto the least loaded workgroup (at most groups_per_block each); the lists go to
 // d_ofs / d_ids for the second launch.
@@ -721,7 +738,8 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     // two phases when there is something to re-deal: enough samples, and several sub-tiles per workgroup
     const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
     const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
-    const uint32_t phases = two_phase ? 2u : 1u;
+    const std::vector<int> stops = phase_stops(two_phase, phase0, R.samples, 2);
+    const uint32_t phases = (uint32_t)stops.size();
     if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes * phases) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     dev::WfView W{};
     W.r0 = scene->pt_r0;
@@ -737,12 +755,12 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
         if (blocks > scene->pt_blocks) scene->pt_blocks = blocks;
         for (uint32_t ph = 0; ph < phases; ph++) {
             RenderView Rp = R;
-            Rp.sample_stop = (two_phase && ph == 0) ? phase0 : R.samples;
-            P.resume = ph;
-            P.group_cost = (two_phase && ph == 0) ? d_cost : nullptr;
+            Rp.sample_stop = stops[ph];
+            P.resume = ph ? 1u : 0u;
+            P.group_cost = ph + 1 < phases ? d_cost : nullptr;   // every phase but the last measures for the next re-deal
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
-            if (ph == 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
+            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             // kernel variant by the features this render can reach (fewer features, fewer spilled registers): the hw7 integrator has no
@@ -815,7 +833,8 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
     }
     const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
     const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
-    const uint32_t phases = two_phase ? 2u : 1u;
+    const std::vector<int> stops = phase_stops(two_phase, phase0, R.samples, 2);
+    const uint32_t phases = (uint32_t)stops.size();
     if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes * phases) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     dev::W6View W{};
     W.r0 = scene->pt6_r0;
@@ -829,12 +848,12 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
         if (blocks > scene->pt_blocks) scene->pt_blocks = blocks;
         for (uint32_t ph = 0; ph < phases; ph++) {
             RenderView Rp = R;
-            Rp.sample_stop = (two_phase && ph == 0) ? phase0 : R.samples;
-            P.resume = ph;
-            P.group_cost = (two_phase && ph == 0) ? d_cost : nullptr;
+            Rp.sample_stop = stops[ph];
+            P.resume = ph ? 1u : 0u;
+            P.group_cost = ph + 1 < phases ? d_cost : nullptr;   // every phase but the last measures for the next re-deal
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
-            if (ph == 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
+            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);

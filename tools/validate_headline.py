@@ -5,7 +5,7 @@ bit, the desynchronised pixels (|difference| > 1e-3 in any channel) and the RMSE
 
     python tools/validate_headline.py --tiles 200 --out gpurun_out/headline_parity.json
 
-Test infrastructure (it calls the oracle); the pytest version of this check replays 8 fixed crops."""
+Test infrastructure (it calls the oracle); the pytest version of this check (tests/test_gpu_scenes.py) replays 100 crops, 4.9 % of the frame."""
 import argparse
 import importlib
 import json

@@ -137,7 +137,7 @@ def test_full_frames_do_not_depend_on_the_walkers_tree(rt, monkeypatch, tmp_path
         assert differing == 0
 
 
-@pytest.mark.parametrize("case", ["identical", "coplanar", "degenerate", "far_from_origin"])
+@pytest.mark.parametrize("case", ["identical", "all_identical", "coplanar", "degenerate", "far_from_origin"])
 def test_builder_edge_cases_render_like_the_reference_topology(rt, monkeypatch, case):
     """Inputs that stress the GPU builder: 120 identical triangles (no split plane separates them: one large leaf), a coplanar sheet (flat
     boxes on one axis, zero centroid extent there), zero-area triangles, and a scene far from the origin (absolute padding and c2 scale
@@ -146,6 +146,8 @@ def test_builder_edge_cases_render_like_the_reference_topology(rt, monkeypatch, 
     rng = np.random.default_rng(5)
     if case == "identical":
         sd.positions[100:220] = sd.positions[100]
+    elif case == "all_identical":                                   # the root cannot be split: one leaf of 400 triangles
+        sd.positions[:] = sd.positions[7]
     elif case == "coplanar":
         sd.positions.reshape(-1, 3, 3)[:300, :, 1] = -1.5           # 300 triangles in the plane y = -1.5
     elif case == "degenerate":

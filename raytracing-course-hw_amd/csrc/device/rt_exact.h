@@ -1,10 +1,17 @@
 // Reference-exact box decisions, shared by the persistent pipeline (rt_persistent.h) and the round pipeline (rt_wavefront.h).
 //
 // The walkers prune with a cheap conservative test on padded boxes, so they find a superset of the triangles the reference's own
-// slab test (hw8/src/primitives.cpp:29-53,163-165: six IEEE divisions on the re-centred, unpadded box) lets through.  A hit is
-// accepted as it stands when the hit point lies robustly inside its triangle's box (pt_box_robust: then every ancestor box
-// passes the reference's test whatever the rounding) and no second triangle was hit within a few ulp of it; the rare others are
-// walked again with the reference's arithmetic over the reference's own trees (ref_closest_hit, ref_light_pdf_sum).
+// slab test (hw8/src/primitives.cpp:29-53,163-165: six IEEE divisions on the re-centred, unpadded box) lets through, and return the
+// closest of them.  That hit stands as the reference's answer (pt_hit_stands) when
+//   (a) every box above it passes the reference's test whatever the rounding (pt_box_robust: margins of the hit point against the
+//       triangle's own box; boxes only grow towards the root), and
+//   (b) the reference's pruning (bvh.h:118, curBest < t_box) cannot have hidden it behind an earlier hit: the runner-up of the walk
+//       lies beyond the hit's window (see pt_hit_stands; the reference's triangle test reports hits outside the triangle's box, and
+//       a hit in a face of a flat box is in the same position within rounding);
+// the rare others (3e-5 of the queries on the benchmark scene) are walked again with the reference's arithmetic over the reference's
+// own trees (ref_closest_hit, ref_light_pdf_sum).  For (b) the walkers must SEE the runner-up whatever tree they walk: look-behind
+// (pt_look_behind_abs, SceneView::cull_k), absolute box padding and reference leaf boxes in host/scene_prep.cpp.  hw6 uses the same gate
+// (rt_persistent_hw6.h).
 #pragma once
 #include "rt_kernels_hw8.h"
 

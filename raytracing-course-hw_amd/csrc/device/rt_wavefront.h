@@ -750,7 +750,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
     return wf_finish_path(S, R, W, slot, levels, tail, rng, sample);
 }
 
-// wf_shade_item behind the exactness gate: a hit that is not robust against the reference's box tests (or has a near tie)
+// wf_shade_item behind the exactness gate (rt_exact.h, pt_hit_stands): a hit that does not stand as the reference's answer
 // and has not been through the exact walk yet goes there first (PT_SHADE_EXACT: nothing of the path's state is touched).
 template <int FEAT = WF_FEAT_ENV | WF_FEAT_HW7>
 RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &W, uint32_t slot, bool &discarded, unsigned long long *counters = nullptr) {

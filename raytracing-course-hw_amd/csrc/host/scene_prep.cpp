@@ -138,7 +138,7 @@ private:
 // face, plus abs_pad = 2^-18 x the largest |coordinate| of scene and camera.  The absolute part is what makes the walk independent of
 // the tree: a triangle test accepts points up to a few ulp OF THE LARGEST COORDINATES INVOLVED outside the true triangle (p = o + t d),
 // so a hit on an edge that lies in a box face at a small coordinate (x = 0: relative padding vanishes) must not be pruned by one
-// tree's boxes and kept by another's — the near-tie flags of the walkers (WF_NEAR_TIE_BIT) rely on every such hit being seen.
+// tree's boxes and kept by another's — the exactness gate (device/rt_exact.h) relies on every such hit, and its runner-up, being seen.
 inline void pad_box(const Box3 &b, float lo[3], float hi[3], float abs_pad) {
     for (int k = 0; k < 3; k++) {
         float mag = smax(std::fabs(b.lo[k]), std::fabs(b.hi[k]));

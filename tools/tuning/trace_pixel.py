@@ -38,8 +38,8 @@ for i in range(n):
     if key not in entries: order.append(key)
     entries[key] = i                                   # a flagged hit comes back verified: keep the last record of a ray
 gpu = [entries[k] for k in order]
-flagged = [i for i in range(n) if hitw[i] != 0xFFFFFFFF and (hitw[i] >> 31) and not verified[i]]
-print(f"{len(flagged)} of {n} consumed records carry the near-tie flag (unverified)")
+flagged = [i for i in range(n) if hitw[i] != 0xFFFFFFFF and verified[i]]
+print(f"{len(flagged)} of {n} consumed records come from the exact walk")
 for i in flagged[:8]:
     print(f"    flagged: o {rec[i, 0:3]} d {rec[i, 3:6]} t {rec[i, 8]!r} figure {hitw[i] & 0x00FFFFFF}")
 orc = oracle_lib.Hw8Oracle(sd)

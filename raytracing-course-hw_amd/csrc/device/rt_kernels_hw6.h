@@ -42,6 +42,22 @@ RT_DEV bool tri6_test(const Tri6Regs &T, F3 o, F3 d, float &t, bool &inside) {
     return true;
 }
 
+// tri6_test for a closest-hit walk that already holds a hit: a plane crossed beyond keep_t (the best t plus the walkers' look-behind,
+// rt_exact.h) can neither win nor matter as the runner-up, so the three edge tests are skipped; same decisions otherwise.
+RT_DEV bool tri6_test_closer(const Tri6Regs &T, F3 o, F3 d, float keep_t, float &t, bool &inside) {
+    F3 ro = o - T.a;
+    float dn = dot(d, T.n);
+    t = -dot(ro, T.n) / dn;
+    if (!(t > 0 && t < RT_T_MAX)) return false;
+    if (t > keep_t) return false;
+    inside = dn > 0;
+    F3 p = ro + t * d;
+    if (dot(crossr(T.b, p), T.n) < 0) return false;
+    if (dot(crossr(p, T.c), T.n) < 0) return false;
+    if (dot(crossr(T.c - T.b, p - T.b), T.n) < 0) return false;
+    return true;
+}
+
 struct Hit6 { int slot; float t; bool inside; uint32_t ref; };
 
 // Wave-synchronous "while-while" walk: the lanes of the wave that are in this call step through inner nodes together until

@@ -321,7 +321,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     if (COUNT) n_tris++;
                     float t; bool inside;
                     // reference tie rule: smallest t, equal t -> lowest index in the reference's figure order
-                    if (tri6_test(T, o, d, t, inside) && t <= cull_t) {
+                    if (tri6_test_closer(T, o, d, cull_t, t, inside)) {
                         if (t < best_t || (t == best_t && T.ref_index < best_ref)) {
                             t2 = fminf(t2, best_t);
                             best_t = t; best_inside = inside; hit = i; best_ref = T.ref_index;

@@ -726,7 +726,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     }
     float4 *d_trace = nullptr;
     const uint32_t trace_cap = 1u << 16;
-    if (count && getenv("RTAMD_TRACE_PIXEL") && getenv("RTAMD_TRACE_OUT")) { // diagnostic: tools/tuning/trace_pixel.py
+    if (count && getenv("RTAMD_TRACE_PIXEL") && getenv("RTAMD_TRACE_OUT")) { // diagnostic: tests/diagnostics/trace_pixel.py
         int tx = 0, ty = 0;
         if (sscanf(getenv("RTAMD_TRACE_PIXEL"), "%d,%d", &tx, &ty) == 2) {
             HIP_CHECK(hipMalloc((void **)&d_trace, (size_t)trace_cap * sizeof(float4)));

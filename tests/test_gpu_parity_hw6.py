@@ -83,7 +83,7 @@ def test_config3_practice6_2_1024x1024x256_crop(rt):
 
 
 def test_full_size_pixels_that_need_the_references_own_box_decisions(rt):
-    """Found by tools/tuning/hw6_fullframe_check.py: seven pixels of a 384x384 crop of the 1024x1024 frame (16 spp) were off by up to 0.33
+    """Found by tests/diagnostics/hw6_fullframe_check.py: seven pixels of a 384x384 crop of the 1024x1024 frame (16 spp) were off by up to 0.33
     before the exactness gate of DESIGN.md 3 was ported to hw6 (hits at a box boundary of the reference's degenerate trees, its pruning
     against hits in a box face).  Here: an 8x8 block around each of them against the oracle, bit for bit."""
     sd = pin_cases.load_hw6("practice6_2")

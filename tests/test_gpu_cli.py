@@ -45,3 +45,20 @@ def test_cli_txt_surface_matches_the_reference_programs_file(tmp_path, snap, sce
 def test_cli_reports_errors(tmp_path):
     r = subprocess.run([MAIN, str(tmp_path / "missing.gltf"), "8", "8", "1", str(tmp_path / "o.ppm")], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "error" in r.stderr
+
+
+def test_cli_fast_build_and_streams(tmp_path):
+    """RTAMD_FAST_BUILD=1 (scene tree on the GPU, load order as the figure order) and RTAMD_STREAMS=k (throughput mode) from the command
+    line: a valid image of the same scene, close to the replayed one in the mean (these frames follow the estimator, not the pixels)."""
+    scene = os.path.join(SCENES, "hw8_sphere", "sphere_emissive.gltf")
+    imgs = []
+    for extra in ({}, {"RTAMD_FAST_BUILD": "1", "RTAMD_STREAMS": "8"}):
+        out = tmp_path / f"o{len(imgs)}.ppm"
+        r = subprocess.run([MAIN, scene, "64", "48", "256", str(out)], capture_output=True, text=True, timeout=300, env=dict(os.environ, **extra))
+        assert r.returncode == 0 and "FINISH" in r.stderr, r.stderr
+        data = out.read_bytes()
+        head = b"P6\n64 48\n255\n"
+        assert data.startswith(head)
+        imgs.append(np.frombuffer(data[len(head):], np.uint8).astype(np.float64).reshape(48, 64, 3))
+    assert not np.array_equal(imgs[0], imgs[1])
+    assert abs(imgs[0].mean() - imgs[1].mean()) <= 0.03 * imgs[0].mean() + 0.5

@@ -36,12 +36,8 @@
 namespace rtamd {
 namespace dev {
 
-// Two workgroups of 640 threads per CU = 5 waves per SIMD at <= 96 VGPRs (amdgpu_waves_per_eu), each with half the LDS: 24-entry stack
-// columns (the rare deeper walk continues in a per-thread global area) and bitmaps for 16,384 paths.
-#define PT_THREADS 640
-#define PT_WAVES 10
-#define PT_STACK 24
-#define PT_OVF 8                      // stack entries per thread beyond PT_STACK (trees up to 32 levels)
+#define PT_THREADS 1024
+#define PT_WAVES 16
 // Experiment: -DPT_TREELET=511 keeps the top 511 nodes of the scene tree (breadth-first, 32,704 B) in LDS; the
 // bitmaps then hold 8,192 paths per workgroup instead of 32,768 so that stacks + bitmaps + treelet fill the 160 KB exactly.
 #ifndef PT_TREELET
@@ -50,7 +46,7 @@ namespace dev {
 #if PT_TREELET
 #define PT_MAX_PATHS 8192
 #else
-#define PT_MAX_PATHS 16384            // paths per workgroup (bitmap capacity in LDS)
+#define PT_MAX_PATHS 32768            // paths per workgroup (bitmap capacity in LDS)
 #endif
 #define PT_NW (PT_MAX_PATHS / 32)
 #define PT_BIT_T 1u                   // pending: closest-hit walk outstanding
@@ -67,7 +63,7 @@ namespace dev {
 #define PT_W_LIGHT 7
 
 struct PtShared {
-    uint32_t stack[PT_WAVES][PT_STACK][64];   // per-lane traversal stack columns, one area per wave
+    uint32_t stack[PT_WAVES][WF_STACK][64];   // per-lane traversal stack columns, one area per wave
     uint32_t need[5][PT_NW];
     uint32_t pending[PT_NW * 2];              // 2 bits per path
     uint32_t groups[PT_MAX_PATHS / 64];       // local 64-slot group -> group of the pass (8x8 sub-tile)
@@ -96,7 +92,6 @@ struct PtParams {
     // COUNT builds, RTAMD_TRACE_PIXEL: every hit record the shader consumes for pixel trace_pixel (= y * width + x) is appended as
     // four float4 (r0..r3 of the path record: ray, hit, packed word); word 0 of trace_buf counts the entries
     float4 *trace_buf; uint32_t trace_cap; int32_t trace_pixel;
-    uint32_t *ovf;                    // PT_OVF stack words per thread
 };
 
 // COUNT builds only: where a wave's time goes (shader-clock cycles per role) and how full its walker iterations are
@@ -200,9 +195,6 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     auto store_hit = [&]() { // the gate (pt_shade_item) decides with the runner-up's t whether this hit needs the exact walk
         wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(S.exact_boxes && hit != WF_MISS ? hit | pt_gap_code(best_t, t2) : hit));
     };
-    uint32_t *const ovf = P.ovf + ((size_t)blockIdx.x * PT_THREADS + threadIdx.x) * PT_OVF;   // the rare walk deeper than the LDS column
-    auto push = [&](uint32_t v) { if (sp < PT_STACK) stack[sp][lane] = v; else if (sp < PT_STACK + PT_OVF) ovf[sp - PT_STACK] = v; sp++; };
-    auto pop = [&]() { --sp; return sp < PT_STACK ? stack[sp][lane] : ovf[min(sp - PT_STACK, PT_OVF - 1)]; };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
@@ -252,14 +244,14 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
                 if (h0 & h1) {
                     bool swap = n1 < n0;
-                    push(swap ? c0 : c1);
+                    stack[sp++][lane] = swap ? c0 : c1;
                     cur = swap ? c1 : c0;
                 } else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) {
                     store_hit();
                     active = false; fin = l;
-                } else cur = pop();
+                } else cur = stack[--sp][lane];
             }
         }
         if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
@@ -285,7 +277,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (sp == 0) {
                 store_hit();
                 active = false; fin = l;
-            } else cur = pop();
+            } else cur = stack[--sp][lane];
         }
     }
 }
@@ -304,12 +296,12 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         active = false;
         if (overflow) { slow = l; return; }
         float v = 0.f;
-        if (k == 1) v = __uint_as_float(stack[PT_STACK - 2][lane]);
-        else if (k == 2) v = __uint_as_float(stack[PT_STACK - 2][lane]) + __uint_as_float(stack[PT_STACK - 4][lane]);
+        if (k == 1) v = __uint_as_float(stack[WF_STACK - 2][lane]);
+        else if (k == 2) v = __uint_as_float(stack[WF_STACK - 2][lane]) + __uint_as_float(stack[WF_STACK - 4][lane]);
         else if (k > 2) { // the reference's association of the additions, see wf_light_loop_lean
             const uint32_t nl = S.n_lights;
             for (int j = 1; j < k; j++) {
-                uint32_t a0 = stack[PT_STACK - 1 - 2 * (j - 1)][lane], b0 = stack[PT_STACK - 1 - 2 * j][lane];
+                uint32_t a0 = stack[WF_STACK - 1 - 2 * (j - 1)][lane], b0 = stack[WF_STACK - 1 - 2 * j][lane];
                 uint32_t len = b0 - a0;
                 uint32_t lv = 31u - (uint32_t)__clz((int)len);
                 uint16_t m0 = S.light_sep[(size_t)lv * nl + a0], m1 = S.light_sep[(size_t)lv * nl + (b0 - (1u << lv))];
@@ -319,14 +311,14 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 int best = 1;
                 uint32_t bd = stack[0][lane];
                 for (int i = 2; i < n; i++) { uint32_t di = stack[i - 1][lane]; if (di > bd) { bd = di; best = i; } }
-                float merged = __uint_as_float(stack[PT_STACK - 2 - 2 * (best - 1)][lane]) + __uint_as_float(stack[PT_STACK - 2 - 2 * best][lane]);
-                stack[PT_STACK - 2 - 2 * (best - 1)][lane] = __float_as_uint(merged);
+                float merged = __uint_as_float(stack[WF_STACK - 2 - 2 * (best - 1)][lane]) + __uint_as_float(stack[WF_STACK - 2 - 2 * best][lane]);
+                stack[WF_STACK - 2 - 2 * (best - 1)][lane] = __float_as_uint(merged);
                 for (int i = best; i < n - 1; i++) {
-                    stack[PT_STACK - 2 - 2 * i][lane] = stack[PT_STACK - 2 - 2 * (i + 1)][lane];
+                    stack[WF_STACK - 2 - 2 * i][lane] = stack[WF_STACK - 2 - 2 * (i + 1)][lane];
                     stack[i - 1][lane] = stack[i][lane];
                 }
             }
-            v = __uint_as_float(stack[PT_STACK - 2][lane]);
+            v = __uint_as_float(stack[WF_STACK - 2][lane]);
         }
         int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
@@ -374,7 +366,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
                 bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= PT_STACK) overflow = true; }
+                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
                 else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) finish();
@@ -389,8 +381,8 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     if (COUNT) n_tris++;
                     float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust);
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
-                        if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= PT_STACK) overflow = true;
-                        else { stack[PT_STACK - 1 - 2 * k][lane] = i; stack[PT_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
+                        if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= WF_STACK) overflow = true;
+                        else { stack[WF_STACK - 1 - 2 * k][lane] = i; stack[WF_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
                     }
                     if (last) break;
                     i++;
@@ -404,7 +396,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
 template <bool COUNT, int FEAT>
-__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void pt_persistent_kernel(SceneView S, RenderView R, WfView W, PtParams P) {
+__global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, RenderView R, WfView W, PtParams P) {
     __shared__ PtShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     PtWave wv;

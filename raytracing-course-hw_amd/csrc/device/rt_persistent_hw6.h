@@ -23,8 +23,6 @@
 namespace rtamd {
 namespace dev {
 
-#define P6_THREADS 1024              // one workgroup of 16 waves per CU (36-entry stack columns fill the LDS)
-#define P6_WAVES 16
 #define P6_STACK 36                  // LDS stack entries per lane (RT6_LDS_STACK: practice6_2's own trees are up to 36 deep)
 #define P6_MAX_PATHS 8192            // paths per workgroup: with 36-entry stacks the bitmaps get 8 KB
 #define P6_NW (P6_MAX_PATHS / 32)
@@ -47,7 +45,7 @@ namespace dev {
 #define P6_EXACT 16                  // the hit does not stand as the reference's answer: exact walk first, nothing of the path was touched
 
 struct P6Shared {
-    uint32_t stack[P6_WAVES][P6_STACK][64];
+    uint32_t stack[PT_WAVES][P6_STACK][64];
     uint32_t need[5][P6_NW];
     uint32_t pending[P6_NW * 2];
     uint32_t groups[P6_MAX_PATHS / 64];
@@ -677,7 +675,7 @@ RT_DEV float ref_light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack
 
 // ---- the kernel (scheduler of rt_persistent.h) ------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(P6_THREADS) void p6_persistent_kernel(SceneView6 S, RenderView R, W6View W, PtParams P) {
+__global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S, RenderView R, W6View W, PtParams P) {
     __shared__ P6Shared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     PtWave wv;
@@ -689,13 +687,13 @@ __global__ __launch_bounds__(P6_THREADS) void p6_persistent_kernel(SceneView6 S,
     wv.nw = n_local_groups * 2u;
     if (wv.n_local == 0u) return;
     for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
-    for (uint32_t i = tid; i < wv.nw; i += P6_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
-    for (uint32_t i = tid; i < 2u * wv.nw; i += P6_THREADS) sh.pending[i] = 0;
-    for (uint32_t i = tid; i < n_local_groups; i += P6_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
+    for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
+    for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
+    for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
     if (tid < 16u) sh.cnt[tid] = 0;
     if (P.debug && tid == 0) { P.debug[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); P.debug[3 * blockIdx.x + 2] = wv.n_local; }
     __syncthreads();
-    for (uint32_t base = 0; base < wv.n_local; base += P6_THREADS) { // seed every pixel, first camera ray (hw6/src/sceneio.cpp:281-284)
+    for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) { // seed every pixel, first camera ray (hw6/src/sceneio.cpp:281-284)
         const uint32_t l = base + tid;
         bool started = false;
         if (l < wv.n_local) {
@@ -853,7 +851,7 @@ __global__ __launch_bounds__(P6_THREADS) void p6_persistent_kernel(SceneView6 S,
     }
     if (P.group_cost) { // every wave leaves the loop once the workgroup's pixels are done (or at the deadline)
         __syncthreads();
-        for (uint32_t i = tid; i < n_local_groups; i += P6_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
+        for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
     }
     if (lane == 0 && P.counters) {
         if (n_closest) atomicAdd(&P.counters[0], (unsigned long long)n_closest);

@@ -97,7 +97,6 @@ struct rt_scene {
     size_t partial_bytes = 0;
     std::vector<hipEvent_t> ev_pool; // brackets every launch of the dominant kernel when stats are requested
     bool device_tree = false;                 // RT_BUILD_DEVICE_BVH: figure order = LOAD order, no reference trees
-    uint32_t *d_pt_ovf = nullptr; size_t pt_ovf_threads = 0; // stack words beyond the LDS columns (PT_OVF per thread)
     unsigned long long *d_pt_debug = nullptr; // persistent pipeline: per workgroup {start, exit time, paths} (RTAMD_DEBUG_COUNTERS)
     float4 *pt_r0 = nullptr;         // persistent pipeline: path records of one pass
     uint32_t *pt_groups = nullptr;   // [cost per group | group_ofs (n_blocks + 1) | group_ids]: the re-deal between the phases of a frame
@@ -120,7 +119,6 @@ struct rt_scene {
         if (pt_groups) (void)hipFree(pt_groups);
         if (pt6_r0) (void)hipFree(pt6_r0);
         if (d_pt_debug) (void)hipFree(d_pt_debug);
-        if (d_pt_ovf) (void)hipFree(d_pt_ovf);
         for (void *p : allocations) (void)hipFree(p);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
@@ -690,7 +688,7 @@ static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_o
 // Every launch is bracketed by events when `time_trace` (ev_pool[2k], ev_pool[2k+1]).
 static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
-    uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", 2 * scene->n_cus); // two 640-thread workgroups per CU (together their LDS fills the CU)
+    uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus); // one 1024-thread workgroup per CU (its LDS fills the CU)
     const uint32_t groups_per_block = PT_MAX_PATHS / 64;
     const uint64_t pass_cap = (uint64_t)n_blocks_max * groups_per_block;
     const uint32_t passes = (uint32_t)((n_work + pass_cap - 1) / pass_cap);
@@ -725,16 +723,6 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     if (getenv("RTAMD_DEBUG_COUNTERS")) {
         if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)1024 * 3 * sizeof(unsigned long long)));
         if (n_blocks_max <= 1024) P.debug = scene->d_pt_debug;
-    }
-    {
-        const size_t threads = (size_t)n_blocks_max * PT_THREADS;
-        if (scene->pt_ovf_threads < threads) {
-            if (scene->d_pt_ovf) (void)hipFree(scene->d_pt_ovf);
-            scene->d_pt_ovf = nullptr; scene->pt_ovf_threads = 0;
-            HIP_CHECK(hipMalloc((void **)&scene->d_pt_ovf, threads * PT_OVF * 4));
-            scene->pt_ovf_threads = threads;
-        }
-        P.ovf = scene->d_pt_ovf;
     }
     float4 *d_trace = nullptr;
     const uint32_t trace_cap = 1u << 16;
@@ -868,8 +856,8 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
             if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
-            if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(P6_THREADS), 0, stream, V, Rp, W, P);
-            else hipLaunchKernelGGL(dev::p6_persistent_kernel<false>, dim3(blocks), dim3(P6_THREADS), 0, stream, V, Rp, W, P);
+            if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
+            else hipLaunchKernelGGL(dev::p6_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch + 1], stream));
             launch++;
         }

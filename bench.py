@@ -378,6 +378,27 @@ def main():
                                                        "note": "untimed side measurement; frames of such a scene are statistically, not pixel-wise, the reference's"}
             except Exception as e:  # the side measurement must not take the bench line down
                 base["config"]["device_built_tree"] = {"error": str(e)}
+            # What the exactness gate costs on this box: the same frame, one untimed render each, without it.
+            try:
+                variants = {}
+                os.environ["RTAMD_KERNEL"] = "wavefront"           # round 1's round pipeline: the conservative walk's answer stands
+                try:
+                    vst = scene.render_device(params, out_rgb.data_ptr(), out_rgb8.data_ptr())
+                finally:
+                    os.environ.pop("RTAMD_KERNEL", None)
+                variants["round_pipeline_without_exactness_gate_msamples_per_s"] = round(vst.samples / vst.kernel_ms / 1e3, 1)
+                os.environ["RTAMD_NO_EXACT_BOXES"] = "1"           # read at scene creation
+                try:
+                    plain = rt.Scene(sd)
+                finally:
+                    os.environ.pop("RTAMD_NO_EXACT_BOXES", None)
+                vst = plain.render_device(params, out_rgb.data_ptr(), out_rgb8.data_ptr())
+                plain.close()
+                variants["persistent_pipeline_without_exactness_gate_msamples_per_s"] = round(vst.samples / vst.kernel_ms / 1e3, 1)
+                variants["note"] = "untimed single renders (kernel time) on the same box; the headline runs with the gate: every pixel the reference's"
+                base["config"]["without_exactness_gate"] = variants
+            except Exception as e:
+                base["config"]["without_exactness_gate"] = {"error": str(e)}
         base["roofline"] = roofline
         base["cpu_baseline"] = cpu
         print(json.dumps(base), flush=True)

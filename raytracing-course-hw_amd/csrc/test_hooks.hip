@@ -2,6 +2,7 @@
 // device functions of rt_device.h on the GPU so tests can compare them with the host libm / libstdc++.
 #include <hip/hip_runtime.h>
 #include "device/rt_device.h"
+#include "device/rt_exact.h"
 
 using namespace rtamd::dev;
 
@@ -19,7 +20,40 @@ __global__ void k_rng(uint32_t seed0, int n_seeds, int n_u, int n_n, float *out)
     for (int i = 0; i < n_n; i++) o[n_u + i] = rng_n01(r);
 }
 
+// rt_exact.h: the runner-up's distance as it travels in the hit word, and the gate's decision on a box / ray / hit / gap
+__global__ void k_gap(const float *t, const float *t2, float *floor_out, uint32_t *code_out, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = pt_gap_code(t[i], t2[i]);
+    code_out[i] = c;
+    floor_out[i] = pt_gap_floor(c | 5u, t[i]);   // some figure index in the low bits: it must not disturb the code
+}
+__global__ void k_stands(const float *in, uint32_t *out, size_t n) { // per case 16 floats: lo.xyz hi.xyz o.xyz d.xyz t gap c2 cull_k
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = in + 16 * i;
+    out[i] = pt_hit_stands(f3(p[0], p[1], p[2]), f3(p[3], p[4], p[5]), f3(p[6], p[7], p[8]), f3(p[9], p[10], p[11]), p[12], p[13], p[14], p[15]) ? 1u : 0u;
+}
+
 extern "C" {
+int rtt_gap_code(const float *t, const float *t2, float *floor_out, uint32_t *code_out, size_t n) {
+    float *d_t = nullptr, *d_t2 = nullptr, *d_f = nullptr; uint32_t *d_c = nullptr;
+    if (hipMalloc((void **)&d_t, n * 4) != hipSuccess || hipMalloc((void **)&d_t2, n * 4) != hipSuccess || hipMalloc((void **)&d_f, n * 4) != hipSuccess || hipMalloc((void **)&d_c, n * 4) != hipSuccess) return -1;
+    (void)hipMemcpy(d_t, t, n * 4, hipMemcpyHostToDevice); (void)hipMemcpy(d_t2, t2, n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_gap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_t, d_t2, d_f, d_c, n);
+    int rc = (hipMemcpy(floor_out, d_f, n * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(code_out, d_c, n * 4, hipMemcpyDeviceToHost) == hipSuccess) ? 0 : -2;
+    (void)hipFree(d_t); (void)hipFree(d_t2); (void)hipFree(d_f); (void)hipFree(d_c);
+    return rc;
+}
+int rtt_hit_stands(const float *cases16, uint32_t *out, size_t n) {
+    float *d_in = nullptr; uint32_t *d_out = nullptr;
+    if (hipMalloc((void **)&d_in, n * 64) != hipSuccess || hipMalloc((void **)&d_out, n * 4) != hipSuccess) return -1;
+    (void)hipMemcpy(d_in, cases16, n * 64, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_stands, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, d_out, n);
+    int rc = hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
+}
 int rtt_logf(const float *in, float *out, size_t n) {
     float *d_in = nullptr, *d_out = nullptr;
     if (hipMalloc((void **)&d_in, n * 4) != hipSuccess || hipMalloc((void **)&d_out, n * 4) != hipSuccess) return -1;

@@ -48,3 +48,52 @@ def test_device_rng_streams_match_libstdcxx(hooks):
         L.rto_rng_kat(s, n_u, n_n, host[s].ctypes.data)
     assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
     assert np.array_equal(dev[0], dev[1])  # seed 0 == seed 1
+
+
+def test_runner_up_gap_code_is_a_floor_within_a_factor_of_two(hooks):
+    """rt_exact.h: the runner-up's distance behind the hit travels in six bits of the hit word as a power of two of t.  The gate works
+    with pt_gap_floor, which must never exceed the true gap (else a hit that needs the exact walk could pass) and stay within 2x."""
+    hooks.rtt_gap_code.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    t = np.exp(rng.uniform(np.log(1e-5), np.log(1e3), 200000)).astype(np.float32)
+    rel = np.exp(rng.uniform(np.log(1e-13), np.log(1e6), t.size)).astype(np.float32)
+    t2 = (t + t * rel).astype(np.float32)
+    t2[:1000] = t[:1000]                                   # exact ties
+    t2[1000:2000] = 2e4                                    # no runner-up (2 x RT_T_MAX)
+    fl = np.zeros_like(t); code = np.zeros(t.size, np.uint32)
+    assert hooks.rtt_gap_code(t.ctypes.data, t2.ctypes.data, fl.ctypes.data, code.ctypes.data, t.size) == 0
+    gap = (t2.astype(np.float64) - t.astype(np.float64))
+    gap32 = (t2 - t).astype(np.float64)                    # what the device subtracts
+    assert np.all((code & ~np.uint32(0x3F000000)) == 0)    # only the six code bits
+    assert np.all(fl.astype(np.float64) <= np.maximum(gap32, 0) * (1 + 1e-6))
+    c = (code >> 24).astype(np.int64)
+    mid = (c > 0) & (c < 63)
+    assert np.all(fl[mid].astype(np.float64) * 2.0000005 >= gap32[mid])   # within a factor of two where the code is not saturated
+    assert np.all(fl[:1000] == 0) and np.all(c[1000:2000] > 40)
+    assert gap.min() >= 0
+
+
+def test_gate_decisions_on_constructed_cases(hooks):
+    """pt_hit_stands on boxes / rays / hits built by hand.  Stands: a hit well inside its box with a distant runner-up; a hit 0.01 in front
+    of its box (the reference's triangle test reports such) with nothing near it; a hit in a flat box with nothing near it.  Does not: an
+    exact tie or a runner-up within 4 ulp; the hit in front of its box with a runner-up inside the window (0.0075 here: the reference
+    prunes the box if that one came first); the flat-box hit and a hit in the entry face of its box with a runner-up 1e-6 / 1e-7 behind."""
+    hooks.rtt_hit_stands.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    c2, k = np.float32(10 * 2.0 ** -20), np.float32(2.0 ** -7)
+    d = np.array([0.3, -0.5, 0.81], np.float64); d /= np.linalg.norm(d)
+    o = np.array([1.0, 6.0, -4.0])
+    def case(lo, hi, t, gap):
+        return [*lo, *hi, *o, *d, t, gap, c2, k]
+    P = lambda t: o + t * d
+    t = 5.0
+    p = P(t)
+    box = (p - 0.05, p + 0.05)
+    flat = (np.array([p[0] - 1, p[1], p[2] - 1]), np.array([p[0] + 1, p[1], p[2] + 1]))     # flat in y, the hit lies in it
+    ahead = (P(t + 0.01) - 0.002, P(t + 0.01) + 0.002)                                       # the ray meets this box only behind the hit
+    edge = (np.array([p[0], p[1] - 0.05, p[2] - 0.05]), np.array([p[0] + 0.05, p[1] + 0.05, p[2] + 0.05]))  # the hit lies in the entry face: window > 0
+    cases = np.array([case(*box, t, 1.0), case(*box, t, 0.0), case(*box, t, 1e-6), case(*ahead, t, 1.0), case(*ahead, t, 0.005),
+                      case(*flat, t, 1.0), case(*flat, t, 1e-6), case(*edge, t, 1e-7)], np.float32)
+    out = np.zeros(len(cases), np.uint32)
+    assert hooks.rtt_hit_stands(cases.ctypes.data, out.ctypes.data, len(cases)) == 0
+    print("gate decisions:", out.tolist())
+    assert out.tolist() == [1, 0, 0, 1, 0, 1, 0, 0]

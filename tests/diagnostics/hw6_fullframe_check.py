@@ -11,6 +11,8 @@ import pin_cases, oracle_lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--crop", type=int, default=384)
+ap.add_argument("--x0", type=int, default=-1)
+ap.add_argument("--y0", type=int, default=-1)
 a = ap.parse_args()
 sd = pin_cases.load_hw6("practice6_2")
 W = H = 1024
@@ -25,7 +27,8 @@ for name in ("device", "host"):
 os.environ.pop("RTAMD_HOST_BVH", None)
 print("pixels on which the two trees differ:", int(np.any(frames["device"] != frames["host"], axis=2).sum()), "of", W * H, flush=True)
 c = a.crop
-x0 = y0 = (W - c) // 2
+x0 = a.x0 if a.x0 >= 0 else (W - c) // 2
+y0 = a.y0 if a.y0 >= 0 else (H - c) // 2
 t0 = time.time()
 ref, _, _ = oracle_lib.Hw6Oracle(sd).render(W, H, a.spp, rect=(x0, y0, c, c))
 got = frames["device"][y0:y0 + c, x0:x0 + c]

@@ -13,7 +13,7 @@
 //   at the end  leaves are laid out in node order (prefix sum), their primitives sorted by load index; inner nodes become two-box
 //               GpuNodes (padded like scene_prep.cpp pad_box) numbered level by level, i.e. the top of the tree is contiguous.
 //
-// The tree depth is bounded (BVB_MAX_DEPTH), so the LDS stack columns of the persistent kernels always fit.  The traversal result does
+// The tree depth is bounded (BvbView::max_depth), so the LDS stack columns of the persistent kernels always fit.  The traversal result does
 // not depend on the tree (closest hit with the tie rule on the reference's figure index where the caller keeps one), which is what makes
 // a tree of our own legitimate for hw6's replay (rt_kernels_hw6.h) and for hw8 scenes built with RT_BUILD_DEVICE_BVH.
 #pragma once
@@ -26,7 +26,7 @@ namespace dev {
 #define BVB_BINS 16
 #define BVB_BIN_WORDS 7                      // count, ~ord(lo.xyz), ord(hi.xyz)
 #define BVB_NODE_BIN_WORDS (3 * BVB_BINS * BVB_BIN_WORDS)
-#define BVB_MAX_DEPTH 28                     // leaves at depth <= 28: a traversal stack of 28 entries is enough
+#define BVB_MAX_DEPTH 28                     // upper bound of BvbView::max_depth (leaves at depth <= max_depth: a traversal stack of that many entries is enough)
 #define BVB_MAX_LEAF 8                       // above this a node is split even when the SAH says "leaf"
 #define BVB_NONE 0xFFFFFFFFu
 #define BVB_THREADS 1024
@@ -63,6 +63,7 @@ struct BvbView {
     uint32_t *order;                         // leaf slot -> primitive
     GpuNode *out_nodes;
     float abs_pad;                           // absolute part of the padding of the emitted boxes (scene_prep.cpp pad_box)
+    uint32_t max_depth;                      // depth limit of this build (<= BVB_MAX_DEPTH): the stack columns of the kernel that will walk the tree
 };
 
 __device__ __forceinline__ uint32_t bvb_ord(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -185,9 +186,9 @@ __global__ void bvb_split_kernel(BvbView B) {
     }
     bool split = best_axis >= 0;
     if (split && count <= BVB_MAX_LEAF && !(best < bvb_half_area(N->lo, N->hi) * (float)count)) split = false; // bvh.h:92-95
-    if (depth >= BVB_MAX_DEPTH) split = false;
+    if (depth >= B.max_depth) split = false;
     // balance guard: a node too large for the levels that are left below it splits where the counts are most even
-    if (split && depth + 2 < BVB_MAX_DEPTH && ((unsigned long long)count * 4ull > (1ull << (BVB_MAX_DEPTH - depth - 2)) * (unsigned long long)BVB_MAX_LEAF)) { best_axis = bal_axis; best_plane = bal_plane; }
+    if (split && depth + 2 < B.max_depth && ((unsigned long long)count * 4ull > (1ull << (B.max_depth - depth - 2)) * (unsigned long long)BVB_MAX_LEAF)) { best_axis = bal_axis; best_plane = bal_plane; }
     BvbDecision D;
     D.split = split ? 1u : 0u; D.axis_plane = 0; D.n_left = 0; D.n_right = 0;
     for (int j = 0; j < 3; j++) { D.llo[j] = 0.f; D.lhi[j] = 0.f; D.rlo[j] = 0.f; D.rhi[j] = 0.f; }

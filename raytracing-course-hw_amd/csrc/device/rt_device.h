@@ -299,7 +299,7 @@ RT_DEV float light_pdf_one(const LightRec *L, F3 x, F3 d, bool &last, bool geome
     return point_prob * len2(x - y) / fabsf(dot(d, sn)); // :68-70 (pdfOne, shading normal in hw8)
 }
 
-template <bool COUNT>
+template <bool COUNT, int STRIDE = 1>
 RT_DEV float light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack, Counters &cnt) {
     if (COUNT) cnt.lightq++;
     RayInv ray = make_ray_inv(x, d);
@@ -333,16 +333,16 @@ RT_DEV float light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack, Coun
             bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
             bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
             uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-            if (h0 & h1) { addmask &= ~(1ull << sp); stack[sp++] = c1; cur = c0; }
+            if (h0 & h1) { addmask &= ~(1ull << sp); stack[STRIDE * sp++] = c1; cur = c0; }
             else if (h0) cur = c0;
             else if (h1) cur = c1;
             else { v = 0.f; descending = false; }
         } else {
             if (sp == 0) break;
             --sp;
-            uint32_t f = stack[sp];
+            uint32_t f = stack[STRIDE * sp];
             if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;       // left total + right total
-            else { addmask |= 1ull << sp; stack[sp++] = __float_as_uint(v); cur = f; descending = true; }
+            else { addmask |= 1ull << sp; stack[STRIDE * sp++] = __float_as_uint(v); cur = f; descending = true; }
         }
     }
     return v;

@@ -59,6 +59,9 @@ RT_DEV RefNodeView load_ref_node(const GpuRefNode *p) {
 // BVH::intersect_ (bvh.h:111-142) as an iterative depth-first walk, left child first: the recursion's `curBest` is the running
 // best of all hits found so far, a leaf keeps its first triangle on equal t, and a later subtree replaces the best only when
 // strictly closer — so one running best with strict '<' reproduces the result.  `stack` holds up to RT_STACK_SIZE node indices.
+// STRIDE: distance in words between consecutive stack entries (1 = a private array; the persistent kernel keeps the stacks of its exact
+// role in LDS, interleaved over the lanes of the batch).
+template <int STRIDE = 1>
 RT_DEV void ref_closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, float &best_t, float &best_u, float &best_v, uint32_t &hit) {
     best_t = RT_T_MAX; best_u = 0.f; best_v = 0.f; hit = WF_MISS;
     if (S.n_tris == 0) return;
@@ -76,15 +79,16 @@ RT_DEV void ref_closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, flo
                         best_t = t; best_u = u; best_v = v; hit = i | (in ? WF_INSIDE_BIT : 0u);
                     }
                 }
-            } else if (sp < RT_STACK_SIZE) { stack[sp++] = n.right; cur = n.left; continue; }
+            } else if (sp < RT_STACK_SIZE) { stack[STRIDE * sp++] = n.right; cur = n.left; continue; }
         }
         if (sp == 0) break;
-        cur = stack[--sp];
+        cur = stack[STRIDE * --sp];
     }
 }
 
 // FiguresMix::getTotalPdf (distributions.h:148-165) over the reference light tree with the reference's box test and its
 // association of the additions (TODO / ADD frames as in light_pdf_sum, rt_device.h).
+template <int STRIDE = 1>
 RT_DEV float ref_light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack) {
     int sp = 0;
     unsigned long long addmask = 0;
@@ -104,14 +108,14 @@ RT_DEV float ref_light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack) 
                 }
                 v = result;
                 descending = false;
-            } else if (sp < RT_STACK_SIZE) { addmask &= ~(1ull << sp); stack[sp++] = n.right; cur = n.left; }
+            } else if (sp < RT_STACK_SIZE) { addmask &= ~(1ull << sp); stack[STRIDE * sp++] = n.right; cur = n.left; }
             else { v = 0.f; descending = false; } // deeper than the host admits (checked there)
         } else {
             if (sp == 0) break;
             --sp;
-            const uint32_t f = stack[sp];
+            const uint32_t f = stack[STRIDE * sp];
             if ((addmask >> sp) & 1ull) v = __uint_as_float(f) + v;                  // left total + right total
-            else { addmask |= 1ull << sp; stack[sp++] = __float_as_uint(v); cur = f; descending = true; }
+            else { addmask |= 1ull << sp; stack[STRIDE * sp++] = __float_as_uint(v); cur = f; descending = true; }
         }
     }
     return v;
@@ -164,13 +168,14 @@ RT_DEV float pt_gap_floor(uint32_t hit, float t) {
     return c ? __uint_as_float((c - 41u + 127u) << 23) * t : 0.f;
 }
 // Absolute part of the walkers' look-behind: the window of a hit that lies inside its box (in_k >= 0) is at most c1 t + c2 max_k 1/|d_k|.
-RT_DEV float pt_look_behind_abs(F3 d, float c2) {
-    return 1.25f * c2 / fmaxf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), 1e-30f);
+// c2x = 1.25f * c2, formed on the host (SceneView::box_c2x): a uniform float product would otherwise sit in a VGPR for the whole launch.
+RT_DEV float pt_look_behind_abs(F3 d, float c2x) {
+    return c2x / fmaxf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), 1e-30f);
 }
 // The gate: does the walkers' hit (t, runner-up at t2) stand as the reference's answer?  Yes when every box above it passes the
 // reference's test robustly (pt_box_robust), the runner-up lies beyond the hit's window and beyond the tie tolerance, and the window
 // does not reach past what the walkers looked at (a hit reported well in front of its own box).
-RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2, float cull_k) {
+RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2, float c2x, float cull_k) {
     const F3 P = o + t * d;
     const float ix = 1.0f / fmaxf(fabsf(d.x), 1e-30f), iy = 1.0f / fmaxf(fabsf(d.y), 1e-30f), iz = 1.0f / fmaxf(fabsf(d.z), 1e-30f);
     const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
@@ -182,7 +187,7 @@ RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2
     const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
     const float exit_ = t + fminf(fminf(bx, by), bz);
     const float window = need - fminf(fminf(ax, ay), az);
-    const float seen = fmaxf(cull_k * t, 1.25f * c2 * fmaxf(fmaxf(ix, iy), iz));   // the walkers' look-behind for this ray and t
+    const float seen = fmaxf(cull_k * t, c2x * fmaxf(fmaxf(ix, iy), iz));   // the walkers' look-behind for this ray and t
     return worst >= need && exit_ >= need && gap > window && gap > 4.8e-7f * (t + gap) && window <= seen; // NaN compares false: exact walk
 }
 

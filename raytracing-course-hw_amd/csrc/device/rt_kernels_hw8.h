@@ -16,13 +16,17 @@ struct Shaded {
     float alpha, metallic;
 };
 
-// Everything Scene::getColor does between the intersection and the direction sampling
-// (scene.cpp:99-149): interpolate attributes, fetch the material, sample the textures, normal map.
-RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
+// The hit triangle's geometric normal, flipped towards the ray's side (primitives.cpp:21-24,123).
+RT_DEV F3 geom_normal(const SceneView &S, const HitRec &h) {
     const float4 *qi = reinterpret_cast<const float4 *>(S.tri_isect + h.idx);
     float4 i0 = qi[0], i1 = qi[1];
     F3 n = f3(i0.w, i1.x, i1.y);
-    ng = normalize(h.inside ? neg(n) : n);               // primitives.cpp:21-24,123
+    return normalize(h.inside ? neg(n) : n);
+}
+
+// Everything Scene::getColor does between the intersection and the direction sampling
+// (scene.cpp:99-149): interpolate attributes, fetch the material, sample the textures, normal map.
+RT_DEV void shade_fetch_attr(const SceneView &S, const HitRec &h, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
     const float4 *q = reinterpret_cast<const float4 *>(S.tri_shade + h.idx);
     float4 s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4], s5 = q[5], s6 = q[6];
     // s0 = n3.xyz dn1.x | s1 = dn1.yz dn2.xy | s2 = dn2.z t3.xyz | s3 = dt1.xyz dt2.x
@@ -62,6 +66,11 @@ RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh,
     float rr = smax(0.08f, m1.w * mr.y);
     sh.alpha = rr * rr;                                                             // :148 pow(.,2.0) == exact square
     sh.metallic = mr.z;                                                             // :149
+}
+
+RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
+    ng = geom_normal(S, h);
+    shade_fetch_attr(S, h, sh, base_color, base_metallic, hw7);
 }
 
 // Only the emission of a hit (scene.cpp:117-125) — all the deepest level of a path can contribute when the

@@ -6,9 +6,10 @@
 // round-based pipeline of rt_wavefront.h runs each stage as a kernel over all pixels and pays a machine-wide drain at every
 // kernel boundary (the launch ends with its longest walk).  Here the dependency is kept PER PATH:
 //
-//   * one 1024-thread workgroup per CU owns a fixed, interleaved share of the pixel slots (8x8 sub-tiles dealt round-robin
-//     to the workgroups); the path records stay in HBM in the layout of rt_wavefront.h, but only this workgroup touches
-//     them, so hand-offs between its waves need workgroup-scope ordering only (one CU, one L1: `s_waitcnt` + LDS);
+//   * five 4-wave workgroups per CU (one wave per SIMD each: five waves per SIMD at <= 96 VGPRs) each own a fixed, interleaved
+//     share of the pixel slots (8x8 sub-tiles dealt round-robin to the workgroups); the path records stay in HBM in the layout
+//     of rt_wavefront.h, but only this workgroup touches them, so hand-offs between its waves need workgroup-scope ordering
+//     only (one CU, one L1: `s_waitcnt` + LDS);
 //   * the stage a path waits for is one bit per path in an LDS bitmap (need_trace / need_light / need_shade / ...); a wave
 //     that wants work claims set bits with LDS atomics (one word per lane, rotating cursor: round-robin service, no
 //     capacity limit, no ring to overflow);
@@ -36,18 +37,16 @@
 namespace rtamd {
 namespace dev {
 
-#define PT_THREADS 1024
+#define PT_THREADS 1024               // hw6 (rt_persistent_hw6.h): one 16-wave workgroup per CU
 #define PT_WAVES 16
-// Experiment: -DPT_TREELET=511 keeps the top 511 nodes of the scene tree (breadth-first, 32,704 B) in LDS; the
-// bitmaps then hold 8,192 paths per workgroup instead of 32,768 so that stacks + bitmaps + treelet fill the 160 KB exactly.
-#ifndef PT_TREELET
-#define PT_TREELET 0
-#endif
-#if PT_TREELET
-#define PT_MAX_PATHS 8192
-#else
-#define PT_MAX_PATHS 32768            // paths per workgroup (bitmap capacity in LDS)
-#endif
+// hw8 / hw7: workgroups of FOUR waves (one per SIMD), FIVE resident per CU = five waves per SIMD.  That takes <= 96 VGPRs per wave (no
+// scratch), 24-entry stack columns (4 x 24 x 256 B = 24 KB per workgroup) and 1 byte of LDS per path for the bitmaps: 31.8 KB per
+// workgroup, five of which fill the CU's 160 KB (handed out in 1,280-byte granules: 25 granules each).
+#define P8_WAVES 4
+#define P8_THREADS (64 * P8_WAVES)
+#define P8_PER_CU 5
+#define P8_STACK 24                   // LDS traversal stack entries per lane; the walkers' tree is built at most this deep (rt_bvh_build.h)
+#define PT_MAX_PATHS 7168             // paths per workgroup (bitmap capacity in LDS): x 1,280 workgroups = 9.2 M, a 3840x2160 frame in one pass
 #define PT_NW (PT_MAX_PATHS / 32)
 #define PT_BIT_T 1u                   // pending: closest-hit walk outstanding
 #define PT_BIT_L 2u                   // pending: light-pdf sum outstanding
@@ -61,18 +60,19 @@ namespace dev {
 #define PT_N_LIVE 5                   // cnt only: pixels of this workgroup not finished yet
 #define PT_W_TRACE 6                  // cnt only: waves currently walking closest hits / light sums
 #define PT_W_LIGHT 7
+#define PT_DEBUG_BLOCKS 2048           // RTAMD_DEBUG_COUNTERS: workgroups whose start / exit times are recorded (>= 256 CUs x 5)
+#define PT_EXACT_BATCH 16             // the exact role walks at most this many queries at once: their stacks (RT_STACK_SIZE entries each) share the wave's LDS stack area
 
 struct PtShared {
-    uint32_t stack[PT_WAVES][WF_STACK][64];   // per-lane traversal stack columns, one area per wave
+    uint32_t stack[P8_WAVES][P8_STACK][64];   // per-lane traversal stack columns, one area per wave
     uint32_t need[5][PT_NW];
     uint32_t pending[PT_NW * 2];              // 2 bits per path
     uint32_t groups[PT_MAX_PATHS / 64];       // local 64-slot group -> group of the pass (8x8 sub-tile)
     uint32_t cost[PT_MAX_PATHS / 64];         // shaded hits per local group in this launch: the load measure the frame is re-dealt by
     int cnt[16];
-#if PT_TREELET
-    float4 treelet[PT_TREELET][4];
-#endif
 };
+static_assert(PT_EXACT_BATCH * RT_STACK_SIZE <= P8_STACK * 64, "the exact role's stacks must fit the wave's LDS stack area");
+static_assert(sizeof(PtShared) <= 25 * 1280, "five workgroups per CU: 25 LDS granules of 1,280 bytes each");
 
 struct PtParams {
     uint32_t n_groups;                // 64-slot groups (8x8 sub-tiles) of this pass
@@ -107,7 +107,14 @@ struct PtWave {
 };
 
 template <class SH> RT_DEV uint32_t pt_slot(const SH &sh, uint32_t l) { return (sh.groups[l >> 6] << 6) | (l & 63u); }
-RT_DEV int pt_count(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // a fresh LDS read each time
+// A fresh LDS read each time; every lane reads the same word, and readfirstlane makes that explicit: the scheduler's decisions are
+// taken on SGPRs (scalar branches, wave-uniform by construction — the code under them uses __ballot / __shfl / lane-0 atomics).
+RT_DEV int pt_count(const int *p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+
+// Number of set bits of a wave mask below this lane (v_mbcnt: no 64-bit lane mask in registers).
+RT_DEV uint32_t pt_rank_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 // Hands paths to the lanes that want one.  The wave reads 64 bitmap words at once (lane i: word cursor + i), then takes whole
 // words in order — ONE atomicAnd per word by lane 0 — and deals the claimed bits to the wanting lanes by rank, so a wave that
@@ -118,9 +125,9 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long wantmask = __ballot(want);
     const int need = __popcll(wantmask);
-    const int my_rank = __popcll(wantmask & ((1ull << lane) - 1ull));
+    const int my_rank = (int)pt_rank_below(wantmask);
     uint32_t got = PT_NONE;
-    int have = 0;
+    int have = 0;                                                 // wave-uniform, like everything below but `got` (readlane / readfirstlane: SGPRs)
     for (uint32_t swept = 0; swept < nw && have < need; swept += 64u) {
         uint32_t w = cursor + lane;
         bool valid = true;
@@ -132,13 +139,13 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
         while (nz && have < need) {
             const int j = __ffsll((long long)nz) - 1;
             nz &= nz - 1ull;
-            const uint32_t vj = (uint32_t)__shfl((int)v, j), wj = (uint32_t)__shfl((int)w, j);
+            const uint32_t vj = (uint32_t)__builtin_amdgcn_readlane((int)v, j), wj = (uint32_t)__builtin_amdgcn_readlane((int)w, j);
             uint32_t rest = vj;                                   // the lowest (need - have) set bits of vj
             for (int n = need - have; n > 0 && rest; n--) rest &= rest - 1u;
             const uint32_t take = vj & ~rest;
             uint32_t old = 0;
             if (lane == 0) old = atomicAnd(&bm[wj], ~take);
-            old = (uint32_t)__shfl((int)old, 0) & take;           // the bits this wave really claimed
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old) & take; // the bits this wave really claimed
             const int c = __popc(old);
             if (want && my_rank >= have && my_rank < have + c) {
                 uint32_t bits = old;
@@ -149,7 +156,7 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
             if (rest) next_cursor = wj;                          // paths left in this word: come back to it first
             else if (have >= need) next_cursor = wj + 1u;
         }
-        cursor = next_cursor;
+        cursor = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_cursor);
         if (cursor >= nw) cursor %= nw;
     }
     if (have && lane == 0) atomicSub(cnt, have);
@@ -217,7 +224,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = make_ray_inv(o, d);
-                    h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2) : 0.f;
+                    h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                     active = true;
                 }
@@ -231,11 +238,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) { prof.trace_iters++; prof.trace_lane_iters += __popcll(__ballot(inner)); }
             if (inner) {
-#if PT_TREELET
-                const float4 *q = cur < (uint32_t)PT_TREELET ? (const float4 *)sh.treelet[cur] : reinterpret_cast<const float4 *>(S.nodes + cur);
-#else
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
-#endif
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 float n0, n1;
@@ -288,20 +291,20 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
     bool active = false, overflow = false, refill_ok = true;
-    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE;
+    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE; // fin: the lane's finished, unpublished path; bit 31 = it needs the exact role instead
     int sp = 0, k = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
-        if (overflow) { slow = l; return; }
+        if (overflow) { fin = l | 0x80000000u; return; }
         float v = 0.f;
-        if (k == 1) v = __uint_as_float(stack[WF_STACK - 2][lane]);
-        else if (k == 2) v = __uint_as_float(stack[WF_STACK - 2][lane]) + __uint_as_float(stack[WF_STACK - 4][lane]);
+        if (k == 1) v = __uint_as_float(stack[P8_STACK - 2][lane]);
+        else if (k == 2) v = __uint_as_float(stack[P8_STACK - 2][lane]) + __uint_as_float(stack[P8_STACK - 4][lane]);
         else if (k > 2) { // the reference's association of the additions, see wf_light_loop_lean
             const uint32_t nl = S.n_lights;
             for (int j = 1; j < k; j++) {
-                uint32_t a0 = stack[WF_STACK - 1 - 2 * (j - 1)][lane], b0 = stack[WF_STACK - 1 - 2 * j][lane];
+                uint32_t a0 = stack[P8_STACK - 1 - 2 * (j - 1)][lane], b0 = stack[P8_STACK - 1 - 2 * j][lane];
                 uint32_t len = b0 - a0;
                 uint32_t lv = 31u - (uint32_t)__clz((int)len);
                 uint16_t m0 = S.light_sep[(size_t)lv * nl + a0], m1 = S.light_sep[(size_t)lv * nl + (b0 - (1u << lv))];
@@ -311,14 +314,14 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 int best = 1;
                 uint32_t bd = stack[0][lane];
                 for (int i = 2; i < n; i++) { uint32_t di = stack[i - 1][lane]; if (di > bd) { bd = di; best = i; } }
-                float merged = __uint_as_float(stack[WF_STACK - 2 - 2 * (best - 1)][lane]) + __uint_as_float(stack[WF_STACK - 2 - 2 * best][lane]);
-                stack[WF_STACK - 2 - 2 * (best - 1)][lane] = __float_as_uint(merged);
+                float merged = __uint_as_float(stack[P8_STACK - 2 - 2 * (best - 1)][lane]) + __uint_as_float(stack[P8_STACK - 2 - 2 * best][lane]);
+                stack[P8_STACK - 2 - 2 * (best - 1)][lane] = __float_as_uint(merged);
                 for (int i = best; i < n - 1; i++) {
-                    stack[WF_STACK - 2 - 2 * i][lane] = stack[WF_STACK - 2 - 2 * (i + 1)][lane];
+                    stack[P8_STACK - 2 - 2 * i][lane] = stack[P8_STACK - 2 - 2 * (i + 1)][lane];
                     stack[i - 1][lane] = stack[i][lane];
                 }
             }
-            v = __uint_as_float(stack[WF_STACK - 2][lane]);
+            v = __uint_as_float(stack[P8_STACK - 2][lane]);
         }
         int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
@@ -328,11 +331,12 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
-            if (__ballot(fin != PT_NONE || slow != PT_NONE)) { // hand-off point, see pt_trace_stint
+            if (__ballot(fin != PT_NONE)) { // hand-off point, see pt_trace_stint
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE);
-                pt_push(sh, PT_Q_XLIGHT, slow, slow != PT_NONE);
-                fin = PT_NONE; slow = PT_NONE;
+                const bool slow = (fin >> 31) != 0u && fin != PT_NONE;
+                pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE && !slow);
+                pt_push(sh, PT_Q_XLIGHT, fin & 0x7FFFFFFFu, slow);
+                fin = PT_NONE;
             }
             if (!refill_ok) {}
             else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
@@ -366,7 +370,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
                 bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= WF_STACK) overflow = true; }
+                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= P8_STACK) overflow = true; }
                 else if (h0) cur = c0;
                 else if (h1) cur = c1;
                 else if (sp == 0) finish();
@@ -381,8 +385,8 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     if (COUNT) n_tris++;
                     float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust);
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
-                        if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= WF_STACK) overflow = true;
-                        else { stack[WF_STACK - 1 - 2 * k][lane] = i; stack[WF_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
+                        if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= P8_STACK) overflow = true;
+                        else { stack[P8_STACK - 1 - 2 * k][lane] = i; stack[P8_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
                     }
                     if (last) break;
                     i++;
@@ -394,11 +398,208 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     }
 }
 
+// ---- the shader role: wf_shade_item / pt_shade_item of rt_wavefront.h laid out for a 96-VGPR budget -----------------------------------
+// Same arithmetic, same order of random draws, same record writes.  What differs is where values wait: the shading code is a chain of
+// sections (finish the pending bounce | hit attributes and textures | Mix::sample | BRDF | Mix::pdf terms | path epilogue), each of
+// which needs 50-75 VGPRs on its own, and only what the *current* section works on stays in registers.  Everything else that a later
+// section needs — the incoming direction, the random engine, base colour x texture colour, the metallic product, a path's tail —
+// is parked in this lane's column of the wave's LDS stack area (idle while the wave shades; volatile accesses, so the compiler neither
+// forwards a parked value through a register nor moves other memory operations across a park / unpark).
+#define PK_TAIL 0                     // 3 words: value the innermost call returns (paths that end)
+#define PK_LEVELS 3                   // bounces below which it returns
+#define PK_RNG 4                      // engine state, saved normal (has_saved travels in the packed word)
+#define PK_D 6                        // incoming direction (3)
+#define PK_BC 9                       // base_color * texture colour (3), metallic * baseMetallic
+#define PK_WORDS 13
+static_assert(PK_WORDS <= P8_STACK, "the shader parks its values in the lane's stack column");
+typedef __attribute__((address_space(3))) volatile uint32_t *PtLdsWord; // an LDS pointer that stays one (32-bit base + immediate offsets)
+struct PtPark {
+    PtLdsWord p;                      // this lane's column: word i at p[64 * i]
+    RT_DEV void put(int i, float v) const { p[64 * i] = __float_as_uint(v); }
+    RT_DEV void putu(int i, uint32_t v) const { p[64 * i] = v; }
+    RT_DEV float get(int i) const { return __uint_as_float(p[64 * i]); }
+    RT_DEV uint32_t getu(int i) const { return p[64 * i]; }
+    RT_DEV void put3(int i, F3 v) const { put(i, v.x); put(i + 1, v.y); put(i + 2, v.z); }
+    RT_DEV F3 get3(int i) const { const float x = get(i), y = get(i + 1), z = get(i + 2); return f3(x, y, z); }
+    RT_DEV Rng rng(uint32_t packed) const { Rng g; g.x = getu(PK_RNG); g.saved = get(PK_RNG + 1); g.has_saved = (packed & 16u) != 0; return g; }
+    RT_DEV void keep(const Rng &g, uint32_t &packed) const { putu(PK_RNG, g.x); put(PK_RNG + 1, g.saved); packed = g.has_saved ? (packed | 16u) : (packed & ~16u); }
+    RT_DEV void end(F3 tail, int levels) const { put3(PK_TAIL, tail); putu(PK_LEVELS, (uint32_t)levels); }
+};
+
+template <int FEAT>
+RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &W, const uint32_t slot, const PtPark pk, bool &discarded) {
+    float4 *r = wf_rec(W, slot);
+    uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
+    {   // the exactness gate (pt_shade_item): a hit that does not stand as the reference's answer goes to the exact walk first, untouched
+        const float4 q0 = r[0], q1 = r[1];
+        if (S.exact_boxes) {
+            const float4 q2 = r[2];
+            const uint32_t hit = __float_as_uint(q2.w);
+            if (hit != WF_MISS && !(packed & WF_VERIFIED_BIT)) {
+                const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
+                const float4 lo = bx[0], hi = bx[1];
+                if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), q2.x, pt_gap_floor(hit, q2.x), S.box_c2, S.box_c2x, S.cull_k))
+                    return PT_SHADE_EXACT;
+            }
+        }
+        pk.put(PK_D, q0.w); pk.put(PK_D + 1, q1.x); pk.put(PK_D + 2, q1.y);
+        pk.putu(PK_RNG, __float_as_uint(q1.z)); pk.put(PK_RNG + 1, q1.w);
+    }
+    int depth = (int)(packed & 15u);
+    bool ended = false;
+    if (packed & WF_PENDING_BIT) {
+        // The bounce at `depth` sampled the ray that was just traced; its pdf is complete now (Mix::pdf, distributions.h:268-278).
+        float4 *e = wf_entry(W, slot, depth);
+        const float4 e0 = e[0], e1 = e[1];
+        const float pdf = e0.w / (float)S.n_components;                             // :278
+        const float k = (float)(1. / (double)pdf * fabs((double)e1.w));             // scene.cpp:159
+        F3 mult = k * f3(e1.x, e1.y, e1.z);
+        const bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
+        if (clamp || depth + 1 >= R.ray_depth) {
+            // clamp hack (scene.cpp:161-163): the path returns the emission and the speculative hit is dropped; at the
+            // last level the inner call returns 0, i.e. emission + mult * 0 evaluated literally.
+            discarded = true; ended = true;
+            if (clamp) pk.end(f3(e0.x, e0.y, e0.z), depth);
+            else { e[1] = make_float4(mult.x, mult.y, mult.z, e1.w); pk.end(f3(0.f, 0.f, 0.f), depth + 1); }
+        } else {
+            bool survives = true;
+            if (R.rr_depth > 0 && depth + 1 >= R.rr_depth) { // Russian roulette (throughput mode only), see wf_shade_item
+                Rng rng = pk.rng(packed);
+                const float q = fminf(1.f, fmaxf(0.05f, fmaxf(mult.x, fmaxf(mult.y, mult.z))));
+                survives = rng_u01(rng) < q;
+                mult = (1.f / q) * mult;
+                pk.keep(rng, packed);
+            }
+            e[1] = make_float4(mult.x, mult.y, mult.z, e1.w);
+            if (survives) depth++;
+            else { discarded = true; ended = true; pk.end(f3(0.f, 0.f, 0.f), depth + 1); }
+        }
+    }
+    if (!ended) {
+        const float4 q2 = r[2];
+        const uint32_t hit = __float_as_uint(q2.w);
+        HitRec h;
+        h.idx = (int)(hit & WF_INDEX_MASK); h.inside = (hit & WF_INSIDE_BIT) != 0; h.t = q2.x; h.u = q2.y; h.v = q2.z;
+        if (hit == WF_MISS) { ended = true; pk.end(miss_color<(FEAT & WF_FEAT_ENV) != 0>(S, pk.get3(PK_D)), depth); }
+        else if (S.last_level_emission_only && depth + 1 >= R.ray_depth) {
+            // Deepest level: getColor returns its emission whatever Mix::sample / brdf / pdf produce (SceneView::last_level_emission_only);
+            // only the random draws must still happen, in order (distributions.h:257, then 3 normals | u1,u2 | index,u,v).
+            pk.end(emission_fetch(S, h), depth);
+            Rng rng = pk.rng(packed);
+            const int comp = (int)(rng_u01(rng) * (float)S.n_components);
+            if (comp == 0) { rng_n01(rng); rng_n01(rng); rng_n01(rng); }
+            else if (comp == 2) { rng_u01(rng); rng_u01(rng); rng_u01(rng); }
+            else { rng_u01(rng); rng_u01(rng); }
+            pk.keep(rng, packed);
+            ended = true;
+        } else {
+            const bool hw7 = (FEAT & WF_FEAT_HW7) && S.hw7;
+            float4 *e = wf_entry(W, slot, depth);
+            {   // the next ray's origin goes to the path's record at once (its final place): x + eps * geomNorma, scene.cpp:104
+                const F3 ng = geom_normal(S, h);
+                const float4 q0 = r[0];
+                const F3 x = f3(q0.x, q0.y, q0.z) + h.t * pk.get3(PK_D);
+                const F3 xo = x + 9.99999974737875163555e-05f * ng;
+                r[0] = make_float4(xo.x, xo.y, xo.z, 0.f);                           // the next ray doubles as the light query
+            }
+            float alpha; F3 sn;
+            {
+                // hit attributes, material, textures (scene.cpp:99-149).  The emission goes to the level's entry at once; colour and
+                // metallic shrink to the products the BRDF uses and wait in the park.
+                F3 base_color; float base_metallic; Shaded sh;
+                shade_fetch_attr(S, h, sh, base_color, base_metallic, hw7);
+                e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, 0.f);
+                pk.put3(PK_BC, base_color * sh.color);
+                pk.put(PK_BC + 3, sh.metallic * base_metallic);
+                alpha = sh.alpha; sn = sh.sn;
+            }
+            F3 nd;
+            {   // Mix::sample (distributions.h:256-265)
+                Rng rng = pk.rng(packed);
+                const int comp = (int)(rng_u01(rng) * (float)S.n_components);         // :257
+                if (comp == 0) nd = cosine_sample(rng, sn);
+                else if (comp == 2) { const float4 xq = r[0]; nd = light_sample(S, rng, f3(xq.x, xq.y, xq.z)); }
+                else nd = vndf_sample(rng, sn, pk.get3(PK_D), alpha);
+                pk.keep(rng, packed);
+            }
+            F3 brdf;
+            {
+                const F3 d = pk.get3(PK_D), bc = pk.get3(PK_BC);
+                const float metallic_eff = pk.get(PK_BC + 3);
+                brdf = hw7 ? material_brdf_hw7(bc, metallic_eff, nd, neg(d), sn, alpha * alpha)
+                           : material_brdf_pre(bc, metallic_eff, nd, neg(d), sn, alpha);
+            }
+            const float epsf = 9.99999974737875163555e-05f;
+            if (brdf.x <= epsf && brdf.y <= epsf && brdf.z <= epsf) {                 // scene.cpp:154-156
+                const float4 e0 = e[0];
+                ended = true; pk.end(f3(e0.x, e0.y, e0.z), depth);
+            } else {
+                e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sn));
+                float pdf = 0.f;                                                       // distributions.h:268-276, first two terms
+                pdf += cosine_pdf(sn, nd);
+                pdf += vndf_pdf(sn, nd, pk.get3(PK_D), alpha);
+                reinterpret_cast<float *>(e)[3] = pdf;
+                reinterpret_cast<float *>(r)[3] = nd.x;
+                r[1] = make_float4(nd.y, nd.z, __uint_as_float(pk.getu(PK_RNG)), pk.get(PK_RNG + 1));
+                const uint32_t sample = (packed >> 6) & WF_SAMPLE_MASK;
+                reinterpret_cast<float *>(r + 3)[3] = __uint_as_float(wf_pack(depth, (packed & 16u) != 0, sample, true));
+                return WF_NEXT_TRACE | (S.n_lights ? WF_NEXT_LIGHT : 0);               // traced speculatively beside its own light-pdf sum
+            }
+        }
+    }
+    Rng rng = pk.rng(packed);
+    return wf_finish_path(S, R, W, slot, (int)pk.getu(PK_LEVELS), pk.get3(PK_TAIL), rng, (packed >> 6) & WF_SAMPLE_MASK);
+}
+
+// ---- the exact role: one lane per query, the reference's own box arithmetic over the reference trees (rt_exact.h) -------------------
+// At most PT_EXACT_BATCH queries of each kind per call; their node stacks live in the wave's (otherwise idle) LDS stack area, entry e of
+// lane i at word e * PT_EXACT_BATCH + i — no scratch.  Rare (3e-5 of the queries), so the partly filled wave does not matter.
+template <class SH>
+RT_DEV void pt_exact_batch(const SceneView &S, const WfView &W, SH &sh, PtWave &wv, uint32_t *area, uint32_t &n_xlight, uint32_t &n_xtrace) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *xstack = area + (lane & (PT_EXACT_BATCH - 1u));
+    uint32_t got = pt_pop(sh.need[PT_Q_XLIGHT], &sh.cnt[PT_Q_XLIGHT], wv.nw, wv.cur[PT_Q_XLIGHT], lane < PT_EXACT_BATCH);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (got != PT_NONE) {
+        const uint32_t slot = pt_slot(sh, got);
+        const float4 *r = wf_rec(W, slot);
+        float4 q0 = r[0], q1 = r[1];
+        const F3 x = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
+        float v;
+        if (S.exact_boxes) v = ref_light_pdf_sum<PT_EXACT_BATCH>(S, x, d, xstack);
+        else { Counters c; c.closest = c.lightq = c.nodes = c.tris = 0; v = light_pdf_sum<false, PT_EXACT_BATCH>(S, x, d, xstack, c); }
+        int depth = (int)(__float_as_uint(r[3].w) & 15u);
+        float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
+        *pdf = *pdf + v / (float)S.n_lights;
+    }
+    n_xlight += __popcll(__ballot(got != PT_NONE));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
+    got = pt_pop(sh.need[PT_Q_XTRACE], &sh.cnt[PT_Q_XTRACE], wv.nw, wv.cur[PT_Q_XTRACE], lane < PT_EXACT_BATCH);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (got != PT_NONE) {
+        const uint32_t slot = pt_slot(sh, got);
+        float4 *r = wf_rec(W, slot);
+        float4 q0 = r[0], q1 = r[1];
+        float bt, bu, bv; uint32_t hit;
+        ref_closest_hit<PT_EXACT_BATCH>(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, bt, bu, bv, hit);
+        r[2] = make_float4(bt, bu, bv, __uint_as_float(hit));
+        float *pk = reinterpret_cast<float *>(r + 3) + 3;
+        *pk = __uint_as_float(__float_as_uint(*pk) | WF_VERIFIED_BIT);
+    }
+    n_xtrace += __popcll(__ballot(got != PT_NONE));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
+// __launch_bounds__(256, 5): five waves per SIMD, i.e. a budget of 96 VGPRs.  Every role fits it without scratch; the scheduler's own
+// state is wave-uniform and lives in SGPRs (pt_count / readfirstlane).
 template <bool COUNT, int FEAT>
-__global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, RenderView R, WfView W, PtParams P) {
+__global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(SceneView S, RenderView R, WfView W, PtParams P) {
     __shared__ PtShared sh;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     PtWave wv;
     wv.n_blocks = gridDim.x; wv.block = blockIdx.x;
     const uint32_t first_group = P.group_ofs ? P.group_ofs[wv.block] : 0u;
@@ -411,16 +612,12 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
     for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
 
     // ---- init: seed every pixel of this workgroup, first camera ray (wf_init_kernel of rt_wavefront.h) -----------------------
-    for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
-    for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
-    for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
+    for (uint32_t i = tid; i < wv.nw; i += P8_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
+    for (uint32_t i = tid; i < 2u * wv.nw; i += P8_THREADS) sh.pending[i] = 0;
+    for (uint32_t i = tid; i < n_local_groups; i += P8_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
     if (tid < 16u) sh.cnt[tid] = 0;
-#if PT_TREELET
-    for (uint32_t i = tid; i < (uint32_t)PT_TREELET * 4u; i += PT_THREADS)
-        sh.treelet[i >> 2][i & 3u] = (i >> 2) < S.n_nodes ? reinterpret_cast<const float4 *>(S.nodes + (i >> 2))[i & 3u] : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
     __syncthreads();
-    for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) {
+    for (uint32_t base = 0; base < wv.n_local; base += P8_THREADS) {
         const uint32_t l = base + tid;
         bool started = false;
         if (l < wv.n_local) {
@@ -466,52 +663,19 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
     uint32_t n_closest = 0, n_light = 0, n_xtrace = 0, n_xlight = 0, n_discarded = 0; // per wave and launch: well below 2^32
     unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t idle_spins = 0;
+    bool gave_up = false;
     PtProf prof;
     unsigned long long t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](unsigned long long &acc) { if (COUNT) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc += t - t_mark; t_mark = t; } };
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { // safety net: never hang the GPU; the host reports the error
-            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
-            break;
-        }
+        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { gave_up = true; break; } // safety net: never hang the GPU; the host reports the error
         const int ns = pt_count(&sh.cnt[PT_Q_SHADE]), nt = pt_count(&sh.cnt[PT_Q_TRACE]), nl = pt_count(&sh.cnt[PT_Q_LIGHT]);
         const int nx = pt_count(&sh.cnt[PT_Q_XLIGHT]) + pt_count(&sh.cnt[PT_Q_XTRACE]);
         if (nx > 0) {
-            // exact role: one lane per query, the reference's own box arithmetic over the reference trees
-            uint32_t xstack[RT_STACK_SIZE];
-            uint32_t got = pt_pop(sh.need[PT_Q_XLIGHT], &sh.cnt[PT_Q_XLIGHT], wv.nw, wv.cur[PT_Q_XLIGHT], true);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (got != PT_NONE) {
-                const uint32_t slot = pt_slot(sh, got);
-                const float4 *r = wf_rec(W, slot);
-                float4 q0 = r[0], q1 = r[1];
-                const F3 x = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
-                float v;
-                if (S.exact_boxes) v = ref_light_pdf_sum(S, x, d, xstack);
-                else { Counters c; c.closest = c.lightq = c.nodes = c.tris = 0; v = light_pdf_sum<false>(S, x, d, xstack, c); }
-                int depth = (int)(__float_as_uint(r[3].w) & 15u);
-                float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
-                *pdf = *pdf + v / (float)S.n_lights;
-            }
-            n_xlight += __popcll(__ballot(got != PT_NONE));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
-            got = pt_pop(sh.need[PT_Q_XTRACE], &sh.cnt[PT_Q_XTRACE], wv.nw, wv.cur[PT_Q_XTRACE], true);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (got != PT_NONE) {
-                const uint32_t slot = pt_slot(sh, got);
-                float4 *r = wf_rec(W, slot);
-                float4 q0 = r[0], q1 = r[1];
-                float bt, bu, bv; uint32_t hit;
-                ref_closest_hit(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, bt, bu, bv, hit);
-                r[2] = make_float4(bt, bu, bv, __uint_as_float(hit));
-                float *pk = reinterpret_cast<float *>(r + 3) + 3;
-                *pk = __uint_as_float(__float_as_uint(*pk) | WF_VERIFIED_BIT);
-            }
-            n_xtrace += __popcll(__ballot(got != PT_NONE));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
+#ifndef DBG_NO_EXACT
+            pt_exact_batch(S, W, sh, wv, &stack[0][0], n_xlight, n_xtrace);
+#endif
             idle_spins = 0;
             lap(prof.t_exact);
             continue;
@@ -533,7 +697,9 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
                     if (4u * k + 5u <= P.trace_cap) for (int q = 0; q < 4; q++) P.trace_buf[1 + 4 * k + q] = tr[q];
                 }
             }
-            if (got != PT_NONE) todo = pt_shade_item<FEAT>(S, R, W, pt_slot(sh, got), discarded);
+#ifndef DBG_NO_SHADE
+            if (got != PT_NONE) { PtPark pk; pk.p = (PtLdsWord)&stack[0][lane]; todo = pt_shade_lean<FEAT>(S, R, W, pt_slot(sh, got), pk, discarded); }
+#endif
             n_discarded += __popcll(__ballot(discarded));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const bool next = got != PT_NONE && (todo & WF_NEXT_TRACE), with_light = next && (todo & WF_NEXT_LIGHT);
@@ -556,12 +722,16 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
             if (P.prio == 1) __builtin_amdgcn_s_setprio(2);
             if (nl == 0 || (nt > 0 && wt >= wl)) {
                 if (lane == 0) atomicAdd(&sh.cnt[PT_W_TRACE], 1);
+#ifndef DBG_NO_TRACE
                 pt_trace_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_closest, n_nodes, n_tris, prof);
+#endif
                 if (lane == 0) atomicSub(&sh.cnt[PT_W_TRACE], 1);
                 lap(prof.t_trace);
             } else {
                 if (lane == 0) atomicAdd(&sh.cnt[PT_W_LIGHT], 1);
+#ifndef DBG_NO_LIGHT
                 pt_light_stint<COUNT>(S, W, sh, P, wv, stack, shade_thr, n_light, n_nodes, n_tris, prof);
+#endif
                 if (lane == 0) atomicSub(&sh.cnt[PT_W_LIGHT], 1);
                 lap(prof.t_light);
             }
@@ -574,14 +744,12 @@ __global__ __launch_bounds__(PT_THREADS) void pt_persistent_kernel(SceneView S, 
         // paths are in flight in other waves' registers: wait for them
         __builtin_amdgcn_s_sleep(8);
         lap(prof.t_idle);
-        if (++idle_spins > (1u << 24)) { // safety net (seconds): never hang the GPU on a lost path; the host reports it
-            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
-            break;
-        }
+        if (++idle_spins > (1u << 24)) { gave_up = true; break; } // safety net (seconds): never hang the GPU on a lost path; the host reports it
     }
+    if (gave_up && lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
     if (P.group_cost) { // every wave leaves the loop once the workgroup's pixels are done (or at the deadline)
         __syncthreads();
-        for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
+        for (uint32_t i = tid; i < n_local_groups; i += P8_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
     }
     if (lane == 0 && P.counters) {
         if (n_closest) atomicAdd(&P.counters[0], (unsigned long long)n_closest);

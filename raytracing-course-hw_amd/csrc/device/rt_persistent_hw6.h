@@ -84,7 +84,7 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
             const uint32_t ref_index = __float_as_uint(reinterpret_cast<const float4 *>(S.tris + ghit)[3].x);
             const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)ref_index;
             const float4 lo = bx[0], hi = bx[1];
-            if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), f3(g0.x, g0.y, g0.z), f3(g0.w, q1.x, q1.y), g2.x, g2.w - g2.x, S.box_c2, S.cull_k)) return P6_EXACT;
+            if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), f3(g0.x, g0.y, g0.z), f3(g0.w, q1.x, q1.y), g2.x, g2.w - g2.x, S.box_c2, S.box_c2x, S.cull_k)) return P6_EXACT;
         }
     }
     F3 ret = f3(0.f, 0.f, 0.f);
@@ -284,7 +284,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = make_ray_inv(o, d);
-                    h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2) : 0.f;
+                    h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     cur = 0; sp = 0; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
                     active = true;
                 }

@@ -94,6 +94,7 @@ struct SceneView {
     const GpuRefNode *ref_nodes, *ref_light_nodes;
     const float *tri_box;          // 8 floats per figure: min.xyz, 0, max.xyz, 0
     float box_c2;
+    float box_c2x;                 // 1.25f * box_c2 (the walkers' absolute look-behind, rt_exact.h)
     uint32_t exact_boxes;          // 0 = accept every hit of the conservative walk (the round pipeline's behaviour)
     uint32_t n_tris, n_lights, n_components;
     uint32_t n_nodes;              // inner nodes of the scene BVH (`nodes`)

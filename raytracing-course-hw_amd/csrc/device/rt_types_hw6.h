@@ -35,7 +35,7 @@ struct SceneView6 {
     const GpuRefNode *ref_nodes, *ref_light_nodes;
     const Tri6 *ref_tris;
     const float *tri_box;
-    float box_c2, cull_k;            // 2^-20 x the largest |coordinate|; the walkers' relative look-behind
+    float box_c2, box_c2x, cull_k;            // 2^-20 x the largest |coordinate|; the walkers' relative look-behind
     uint32_t exact_boxes;
     const GpuMaterial6 *materials;
     uint32_t n_tris, n_lights, n_components;

@@ -303,7 +303,7 @@ RT_DEV void wf_trace_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 float4 q0 = r[0], q1 = r[1];
                 o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                 ray = make_ray_inv(o, d);
-                h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2) : 0.f;
+                h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                 cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                 active = true;
                 if (COUNT) ray_start = w_iter;
@@ -764,7 +764,7 @@ RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &
             const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);
             const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
             const float4 lo = bx[0], hi = bx[1];
-            if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), o, d, q2.x, pt_gap_floor(hit, q2.x), S.box_c2, S.cull_k)) return PT_SHADE_EXACT;
+            if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), o, d, q2.x, pt_gap_floor(hit, q2.x), S.box_c2, S.box_c2x, S.cull_k)) return PT_SHADE_EXACT;
         }
     }
     return wf_shade_item<FEAT>(S, R, W, slot, counters, &discarded);

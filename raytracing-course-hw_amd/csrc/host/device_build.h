@@ -15,8 +15,9 @@ struct DeviceTree {
 };
 
 // d_boxes: 8 floats per primitive (lo.xyz, -, hi.xyz, -) on the current device; n >= 1.  Synchronous.  Throws HipError.
-// abs_pad: absolute part of the node boxes' padding (scene_prep.cpp pad_box).
-DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad);
+// abs_pad: absolute part of the node boxes' padding (scene_prep.cpp pad_box).  max_depth (8..28): no leaf lies deeper, so a traversal
+// stack of max_depth entries is enough (the LDS stack columns of the kernel that walks the tree).
+DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad, uint32_t max_depth);
 void free_device_tree(DeviceTree &t);
 
 // out[i] = in[order[i]] for records of elem_bytes (a multiple of 16); then the 32-bit word at mark_word_offset of every record becomes

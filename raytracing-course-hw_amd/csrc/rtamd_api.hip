@@ -240,7 +240,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                 DeviceTree t;
                 Tri6 *d_tris = nullptr;
                 try {
-                    t = build_tree_on_device(d_boxes, desc->n_triangles, P6.box_pad);
+                    t = build_tree_on_device(d_boxes, desc->n_triangles, P6.box_pad, 28); // hw6 walkers: 36-entry stack columns
                     HIP_CHECK(hipMalloc((void **)&d_tris, (size_t)desc->n_triangles * sizeof(Tri6)));
                     gather_records(d_load, d_tris, t, desc->n_triangles, sizeof(Tri6), 13); // word 13 = Tri6::last
                     HIP_CHECK(hipDeviceSynchronize());
@@ -274,7 +274,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             V.ref_light_nodes = keep(upload(P6.ref_light_nodes, bytes));
             V.ref_tris = keep(upload(P6.ref_tris, bytes));
             V.tri_box = keep(upload(P6.tri_box, bytes));
-            V.box_c2 = P6.box_c2;
+            V.box_c2 = P6.box_c2; V.box_c2x = 1.25f * P6.box_c2;
             V.cull_k = getenv("RTAMD_CULL_K") ? (float)atof(getenv("RTAMD_CULL_K")) : 0.0078125f;
             V.exact_boxes = getenv("RTAMD_NO_EXACT_BOXES") ? 0u : 1u;
             V.light_sep = keep(upload(P6.light_sep, bytes));
@@ -332,9 +332,9 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                 if (!P.walk_box.empty()) { // reference leaf boxes (scene_prep.h)
                     uint64_t scratch = 0;
                     float *d_walk_box = upload(P.walk_box, scratch);
-                    try { t = build_tree_on_device(d_walk_box, n, P.box_pad); } catch (...) { (void)hipFree(d_walk_box); throw; }
+                    try { t = build_tree_on_device(d_walk_box, n, P.box_pad, P8_STACK); } catch (...) { (void)hipFree(d_walk_box); throw; }
                     (void)hipFree(d_walk_box);
-                } else t = build_tree_on_device(V.tri_box, n, P.box_pad);
+                } else t = build_tree_on_device(V.tri_box, n, P.box_pad, P8_STACK); // no deeper than the persistent kernel's stack columns
                 HIP_CHECK(hipMalloc((void **)&d_walk, (size_t)n * sizeof(TriIsect)));
                 gather_records(V.tri_isect, d_walk, t, n, sizeof(TriIsect), 11, true); // word 11 = TriIsect::pad: figure index << 1 | leaf mark
                 HIP_CHECK(hipDeviceSynchronize());
@@ -363,7 +363,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         V.light_sep = keep(upload(P.light_sep, bytes));
         V.ref_nodes = keep(upload(P.ref_nodes, bytes));
         V.ref_light_nodes = keep(upload(P.ref_light_nodes, bytes));
-        V.box_c2 = P.box_c2;
+        V.box_c2 = P.box_c2; V.box_c2x = 1.25f * P.box_c2;
         // how far behind the best hit the walkers still look, relative to t (rt_exact.h)
         V.cull_k = getenv("RTAMD_CULL_K") ? (float)atof(getenv("RTAMD_CULL_K")) : 0.0078125f;
         V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || fast_build) ? 0u : 1u; // RT_BUILD_DEVICE_BVH: there is no reference tree to be exact about
@@ -688,7 +688,7 @@ static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_o
 // Every launch is bracketed by events when `time_trace` (ev_pool[2k], ev_pool[2k+1]).
 static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
-    uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus); // one 1024-thread workgroup per CU (its LDS fills the CU)
+    uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus * P8_PER_CU); // five 4-wave workgroups per CU (their LDS fills the CU)
     const uint32_t groups_per_block = PT_MAX_PATHS / 64;
     const uint64_t pass_cap = (uint64_t)n_blocks_max * groups_per_block;
     const uint32_t passes = (uint32_t)((n_work + pass_cap - 1) / pass_cap);
@@ -721,8 +721,8 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
     P.debug = nullptr;
     if (getenv("RTAMD_DEBUG_COUNTERS")) {
-        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)1024 * 3 * sizeof(unsigned long long)));
-        if (n_blocks_max <= 1024) P.debug = scene->d_pt_debug;
+        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
+        if (n_blocks_max <= PT_DEBUG_BLOCKS) P.debug = scene->d_pt_debug;
     }
     float4 *d_trace = nullptr;
     const uint32_t trace_cap = 1u << 16;
@@ -761,12 +761,12 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
             if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
-            if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
+            if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             // kernel variant by the features this render can reach (fewer features, fewer spilled registers): the hw7 integrator has no
             // environment map; an hw8 render needs the environment lookup only when the scene has a map
             const int feat = V.hw7 ? WF_FEAT_HW7 : (V.env_image >= 0 ? WF_FEAT_ENV : 0);
-            const dim3 grid(blocks), block(PT_THREADS);
+            const dim3 grid(blocks), block(P8_THREADS);
             if (count) {
                 if (feat == WF_FEAT_HW7) hipLaunchKernelGGL((dev::pt_persistent_kernel<true, WF_FEAT_HW7>), grid, block, 0, stream, V, Rp, W, P);
                 else if (feat == WF_FEAT_ENV) hipLaunchKernelGGL((dev::pt_persistent_kernel<true, WF_FEAT_ENV>), grid, block, 0, stream, V, Rp, W, P);
@@ -828,8 +828,8 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
     P.counters = scene->d_counters;
     P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
     if (getenv("RTAMD_DEBUG_COUNTERS")) {
-        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)1024 * 3 * sizeof(unsigned long long)));
-        if (n_blocks_max <= 1024) P.debug = scene->d_pt_debug;
+        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
+        if (n_blocks_max <= PT_DEBUG_BLOCKS) P.debug = scene->d_pt_debug;
     }
     const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
     const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
@@ -854,7 +854,7 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
             if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
-            if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)1024 * 3 * sizeof(unsigned long long), stream));
+            if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
             else hipLaunchKernelGGL(dev::p6_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
@@ -942,7 +942,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         // tree takes ~1.5 ms; RTAMD_ROUNDS_EXACT=1 switches them on for testing).  RTAMD_AUTO_GROUPS_PER_CU=n: opt into the round
         // pipeline from n sub-tiles per CU on.
         bool use_persistent = use_wavefront && !(ksel && strcmp(ksel, "wavefront") == 0) &&
-                              scene->info.bvh_depth <= WF_STACK && scene->info.light_bvh_depth <= WF_STACK && !getenv("RTAMD_WF_LDS_STACK");
+                              scene->info.bvh_depth <= P8_STACK && scene->info.light_bvh_depth <= P8_STACK && !getenv("RTAMD_WF_LDS_STACK");
         if (use_persistent && !ksel) {
             const uint64_t auto_groups = (uint64_t)(getenv("RTAMD_AUTO_GROUPS_PER_CU") ? atoi(getenv("RTAMD_AUTO_GROUPS_PER_CU")) : 0);
             if (auto_groups && (uint64_t)n_work * (uint64_t)streams >= auto_groups * (uint64_t)scene->n_cus) use_persistent = false;
@@ -1053,7 +1053,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 fprintf(stderr, "[rtamd] persistent hw6 kernel, wave time by role: closest-hit walks %.1f %%, light walks %.1f %%, shading %.1f %%, slow light sums %.1f %%, idle %.1f %%\n",
                         100 * h_cnt[16] / tt, 100 * h_cnt[17] / tt, 100 * h_cnt[18] / tt, 100 * h_cnt[19] / tt, 100 * h_cnt[20] / tt);
             }
-            if (scene->d_pt_debug && scene->pt_blocks <= 1024) {
+            if (scene->d_pt_debug && scene->pt_blocks <= PT_DEBUG_BLOCKS) {
                 std::vector<unsigned long long> dbg((size_t)scene->pt_blocks * 3);
                 HIP_CHECK(hipMemcpy(dbg.data(), scene->d_pt_debug, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
                 unsigned long long t0 = ~0ull, tmin = ~0ull, tmax = 0; double tsum = 0;
@@ -1068,7 +1068,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (use_persistent) {
             if (h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");
             h_cnt[0] -= h_cnt[10] < h_cnt[0] ? h_cnt[10] : h_cnt[0]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
-            if (getenv("RTAMD_DEBUG_COUNTERS") && scene->d_pt_debug && scene->pt_blocks <= 1024) {
+            if (getenv("RTAMD_DEBUG_COUNTERS") && scene->d_pt_debug && scene->pt_blocks <= PT_DEBUG_BLOCKS) {
                 std::vector<unsigned long long> dbg((size_t)scene->pt_blocks * 3);
                 HIP_CHECK(hipMemcpy(dbg.data(), scene->d_pt_debug, dbg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
                 unsigned long long t0 = ~0ull, tmin = ~0ull, tmax = 0; double tsum = 0;

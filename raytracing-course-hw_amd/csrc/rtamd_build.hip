@@ -21,11 +21,12 @@ __global__ void gather16_kernel(const float4 *in, float4 *out, const uint32_t *o
 }
 } // namespace
 
-DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad) {
+DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad, uint32_t max_depth) {
     DeviceTree t;
     if (n == 0) throw std::runtime_error("build_tree_on_device: no primitives");
     dev::BvbView B{};
-    B.boxes = d_boxes; B.n = n; B.abs_pad = abs_pad;
+    if (max_depth < 8 || max_depth > BVB_MAX_DEPTH) throw std::runtime_error("build_tree_on_device: max_depth out of range");
+    B.boxes = d_boxes; B.n = n; B.abs_pad = abs_pad; B.max_depth = max_depth;
     const size_t max_open = (size_t)n / 2 + 2, max_nodes = 2 * (size_t)n + 2;
     std::vector<void *> temps;
     auto alloc = [&](size_t bytes, bool temp) { void *p = nullptr; HIP_CHECK(hipMalloc(&p, bytes)); if (temp) temps.push_back(p); return p; };
@@ -49,7 +50,7 @@ DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad)
         const uint32_t prim_blocks = (n + 255) / 256, prim_wgs = (n + BVB_THREADS - 1) / BVB_THREADS, open_blocks = (uint32_t)((max_open + 255) / 256);
         hipLaunchKernelGGL(dev::bvb_init_kernel, dim3(prim_blocks), dim3(256), 0, stream, B);
         hipLaunchKernelGGL(dev::bvb_root_kernel, dim3(1), dim3(64), 0, stream, B);
-        for (int level = 0; level <= BVB_MAX_DEPTH; level++) {
+        for (int level = 0; level <= (int)max_depth; level++) {
             hipLaunchKernelGGL(dev::bvb_bin_kernel, dim3(prim_wgs), dim3(BVB_THREADS), 0, stream, B);
             hipLaunchKernelGGL(dev::bvb_split_kernel, dim3(open_blocks), dim3(256), 0, stream, B);
             hipLaunchKernelGGL(dev::bvb_number_kernel, dim3(1), dim3(BVB_THREADS), 0, stream, B);

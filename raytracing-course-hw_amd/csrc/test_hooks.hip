@@ -32,7 +32,7 @@ __global__ void k_stands(const float *in, uint32_t *out, size_t n) { // per case
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = in + 16 * i;
-    out[i] = pt_hit_stands(f3(p[0], p[1], p[2]), f3(p[3], p[4], p[5]), f3(p[6], p[7], p[8]), f3(p[9], p[10], p[11]), p[12], p[13], p[14], p[15]) ? 1u : 0u;
+    out[i] = pt_hit_stands(f3(p[0], p[1], p[2]), f3(p[3], p[4], p[5]), f3(p[6], p[7], p[8]), f3(p[9], p[10], p[11]), p[12], p[13], p[14], 1.25f * p[14], p[15]) ? 1u : 0u;
 }
 
 extern "C" {

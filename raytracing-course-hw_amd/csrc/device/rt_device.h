@@ -484,16 +484,21 @@ RT_DEV Quat vndf_getq(F3 n) { // :212-224
     q.w = w / l;
     return q;
 }
-RT_DEV F3 vndf_sample_local(Rng &rng, F3 v, float alpha) { // :170-194 (Heitz 2018)
+// The two uniform draws of the sampler and the point they give on the unit disk (:178-182).  Split from the rest so that a caller can
+// take the draws — and the double-precision sin / cos, the register-hungriest part — before it builds the frame around v: the random
+// stream and every value are the same in either order.
+RT_DEV void vndf_disk_point(Rng &rng, float &t1, float &t2) {
+    float u1 = rng_u01(rng), u2 = rng_u01(rng);
+    float r = sqrtf(u1);
+    float phi = (float)(2.0 * RT_PI * (double)u2);
+    t1 = (float)((double)r * cos((double)phi));
+    t2 = (float)((double)r * sin((double)phi));
+}
+RT_DEV F3 vndf_sample_local(float t1, float t2, F3 v, float alpha) { // :170-194 (Heitz 2018)
     F3 vh = normalize(f3(alpha * v.x, alpha * v.y, v.z));
     float lensq = vh.x * vh.x + vh.y * vh.y;
     F3 T1 = lensq > 0 ? (float)(1. / sqrt((double)lensq)) * f3(-vh.y, vh.x, 0.f) : f3(1.f, 0.f, 0.f);
     F3 T2 = crossr(T1, vh);
-    float u1 = rng_u01(rng), u2 = rng_u01(rng);
-    float r = sqrtf(u1);
-    float phi = (float)(2.0 * RT_PI * (double)u2);
-    float t1 = (float)((double)r * cos((double)phi));
-    float t2 = (float)((double)r * sin((double)phi));
     float s = 0.5f * (1.0f + vh.z);
     t2 = (float)((1.0 - (double)s) * sqrt((double)(1.f - t1 * t1)) + (double)(s * t2));
     float rem = (float)(1.0 - (double)(t1 * t1) - (double)(t2 * t2));
@@ -516,10 +521,12 @@ RT_DEV float vndf_pdf_local(F3 d, F3 v, float a) { // :205-210
     return dv / (4 * dot(v, ni));
 }
 RT_DEV F3 vndf_sample(Rng &rng, F3 n, F3 v, float alpha) { // :229-237
+    float t1, t2;
+    vndf_disk_point(rng, t1, t2);
     v = neg(v);
     Quat q = vndf_getq(n);
     F3 vT = qtransform(q, v);
-    F3 dT = vndf_sample_local(rng, vT, alpha);
+    F3 dT = vndf_sample_local(t1, t2, vT, alpha);
     return qtransform(qconj(q), dT);
 }
 RT_DEV float vndf_pdf(F3 n, F3 d, F3 v, float alpha) { // :239-245

@@ -27,41 +27,57 @@ RT_DEV F3 geom_normal(const SceneView &S, const HitRec &h) {
 // Everything Scene::getColor does between the intersection and the direction sampling
 // (scene.cpp:99-149): interpolate attributes, fetch the material, sample the textures, normal map.
 RT_DEV void shade_fetch_attr(const SceneView &S, const HitRec &h, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
+    // TriShade: s0 = n3.xyz dn1.x | s1 = dn1.yz dn2.xy | s2 = dn2.z t3.xyz | s3 = dt1.xyz dt2.x
+    //           s4 = dt2.yz uv3.xy | s5 = duv1.xy duv2.xy | s6 = tanw material orig pad
+    // Read in the order of use — texture coordinates and material first, normal and tangent bases after the texture taps — so that the
+    // bases do not sit in registers while the taps run (the interpolations themselves are the reference's, primitives.cpp:110-119).
     const float4 *q = reinterpret_cast<const float4 *>(S.tri_shade + h.idx);
-    float4 s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4], s5 = q[5], s6 = q[6];
-    // s0 = n3.xyz dn1.x | s1 = dn1.yz dn2.xy | s2 = dn2.z t3.xyz | s3 = dt1.xyz dt2.x
-    // s4 = dt2.yz uv3.xy | s5 = duv1.xy duv2.xy | s6 = tanw material orig pad
-    F3 n3 = f3(s0.x, s0.y, s0.z), dn1 = f3(s0.w, s1.x, s1.y), dn2 = f3(s1.z, s1.w, s2.x);
-    F3 t3 = f3(s2.y, s2.z, s2.w), dt1 = f3(s3.x, s3.y, s3.z), dt2 = f3(s3.w, s4.x, s4.y);
-    float u = h.u, v = h.v;
-    F3 sn = n3 + u * dn1 + v * dn2;                       // primitives.cpp:110
-    float tu = s4.z + u * s5.x + v * s5.z;                // :111-114
-    float tv = s4.w + u * s5.y + v * s5.w;
-    F3 tg = t3 + u * dt1 + v * dt2;                       // :115
-    tg = normalize(tg);                                   // :116
-    sn = normalize(sn);                                   // :117
-    if (h.inside) sn = neg(sn);                           // :118-119
-    float tanw = s6.x;
-    uint32_t mat = __float_as_uint(s6.y);
+    const float u = h.u, v = h.v;
+    float tu, tv, tanw; uint32_t mat;
+    {
+        const float4 s4 = q[4], s5 = q[5], s6 = q[6];
+        tu = s4.z + u * s5.x + v * s5.z;                  // :111-114
+        tv = s4.w + u * s5.y + v * s5.w;
+        tanw = s6.x;
+        mat = __float_as_uint(s6.y);
+    }
     const float4 *qm = reinterpret_cast<const float4 *>(S.materials + mat);
     float4 m0 = qm[0], m1 = qm[1], m2 = qm[2];
     base_color = f3(m0.x, m0.y, m0.z); base_metallic = m0.w;
     int tex_color = (int)__float_as_uint(m2.x), tex_emis = (int)__float_as_uint(m2.y);
     int tex_mr = (int)__float_as_uint(m2.z), tex_nrm = (int)__float_as_uint(m2.w);
+    F3 mr = f3(1.f, 1.f, 1.f), ns = f3(0.5f, 0.5f, 1.f);
+    sh.color = f3(1.f, 1.f, 1.f);
+    sh.emission = f3(m1.x, m1.y, m1.z);
+    if (!hw7) {
+        if (tex_color >= 0) sh.color = sample_texture(S, tex_color, tu, tv, true);      // scene.cpp:107-115
+        if (tex_emis >= 0) sh.emission = sh.emission * sample_texture(S, tex_emis, tu, tv, true); // :117-125
+        if (tex_mr >= 0) mr = sample_texture(S, tex_mr, tu, tv, false);                 // :127-135
+        if (tex_nrm >= 0) ns = sample_texture(S, tex_nrm, tu, tv, false);               // :137-145
+    }
+    F3 sn;
+    {
+        const float4 s0 = q[0], s1 = q[1];
+        const float s2x = reinterpret_cast<const float *>(q + 2)[0];
+        const F3 n3 = f3(s0.x, s0.y, s0.z), dn1 = f3(s0.w, s1.x, s1.y), dn2 = f3(s1.z, s1.w, s2x);
+        sn = n3 + u * dn1 + v * dn2;                      // primitives.cpp:110
+        sn = normalize(sn);                               // :117
+        if (h.inside) sn = neg(sn);                       // :118-119
+    }
     if (hw7) { // hw7/src/scene.cpp:29-61: factors only
-        sh.color = f3(1.f, 1.f, 1.f); sh.emission = f3(m1.x, m1.y, m1.z); sh.sn = sn;
+        sh.sn = sn;
         sh.alpha = m1.w * m1.w;                                                      // pow(roughnessFactor, 2.0), :44
         sh.metallic = 1.f;
         return;
     }
-    sh.color = f3(1.f, 1.f, 1.f);
-    if (tex_color >= 0) sh.color = sample_texture(S, tex_color, tu, tv, true);      // scene.cpp:107-115
-    sh.emission = f3(m1.x, m1.y, m1.z);
-    if (tex_emis >= 0) sh.emission = sh.emission * sample_texture(S, tex_emis, tu, tv, true); // :117-125
-    F3 mr = f3(1.f, 1.f, 1.f);
-    if (tex_mr >= 0) mr = sample_texture(S, tex_mr, tu, tv, false);                 // :127-135
-    F3 ns = f3(0.5f, 0.5f, 1.f);
-    if (tex_nrm >= 0) ns = sample_texture(S, tex_nrm, tu, tv, false);               // :137-145
+    F3 tg;
+    {
+        const float4 s2 = q[2], s3 = q[3];
+        const float2 s4xy = reinterpret_cast<const float2 *>(q + 4)[0];
+        const F3 t3 = f3(s2.y, s2.z, s2.w), dt1 = f3(s3.x, s3.y, s3.z), dt2 = f3(s3.w, s4xy.x, s4xy.y);
+        tg = t3 + u * dt1 + v * dt2;                      // :115
+        tg = normalize(tg);                               // :116
+    }
     sh.sn = apply_normal_map(sn, tg, tanw, ns);                                     // :146
     float rr = smax(0.08f, m1.w * mr.y);
     sh.alpha = rr * rr;                                                             // :148 pow(.,2.0) == exact square

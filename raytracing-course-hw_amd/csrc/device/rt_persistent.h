@@ -60,6 +60,11 @@ namespace dev {
 #define PT_N_LIVE 5                   // cnt only: pixels of this workgroup not finished yet
 #define PT_W_TRACE 6                  // cnt only: waves currently walking closest hits / light sums
 #define PT_W_LIGHT 7
+// What a sub-tile costs its workgroup, in units of one closest-hit node step (wave time by role over steps by role on the benchmark
+// scene): the measure the frame is re-dealt by after its first phase.  Counting shaded hits alone misses the rays that hit nothing.
+#define PT_COST_TRACE_STEP 1u
+#define PT_COST_LIGHT_STEP 2u
+#define PT_COST_SHADE 14u
 #define PT_DEBUG_BLOCKS 2048           // RTAMD_DEBUG_COUNTERS: workgroups whose start / exit times are recorded (>= 256 CUs x 5)
 #define PT_EXACT_BATCH 16             // the exact role walks at most this many queries at once: their stacks (RT_STACK_SIZE entries each) share the wave's LDS stack area
 
@@ -68,7 +73,7 @@ struct PtShared {
     uint32_t need[5][PT_NW];
     uint32_t pending[PT_NW * 2];              // 2 bits per path
     uint32_t groups[PT_MAX_PATHS / 64];       // local 64-slot group -> group of the pass (8x8 sub-tile)
-    uint32_t cost[PT_MAX_PATHS / 64];         // shaded hits per local group in this launch: the load measure the frame is re-dealt by
+    uint32_t cost[PT_MAX_PATHS / 64];         // work done for each local group in this launch (PT_COST_*): the load measure the frame is re-dealt by
     int cnt[16];
 };
 static_assert(PT_EXACT_BATCH * RT_STACK_SIZE <= P8_STACK * 64, "the exact role's stacks must fit the wave's LDS stack area");
@@ -193,6 +198,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     bool active = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
     int sp = 0;
+    uint32_t steps = 0;   // node steps + triangle tests of the lane's current walk: the cost measure of the re-deal (PT_COST_*)
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
@@ -201,6 +207,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     float cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // h_ray: absolute part of the look-behind (pt_look_behind)
     auto store_hit = [&]() { // the gate (pt_shade_item) decides with the runner-up's t whether this hit needs the exact walk
         wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(S.exact_boxes && hit != WF_MISS ? hit | pt_gap_code(best_t, t2) : hit));
+        if (P.group_cost) atomicAdd(&sh.cost[l >> 6], steps * PT_COST_TRACE_STEP);
     };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -225,6 +232,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = make_ray_inv(o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
+                    steps = 0;
                     cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                     active = true;
                 }
@@ -241,6 +249,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
+                steps++;
                 float n0, n1;
                 bool h0 = slab_test(lo0, hi0, ray, cull_t, n0);
                 bool h1 = slab_test(lo1, hi1, ray, cull_t, n1);
@@ -263,6 +272,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 for (;;) {
                     TriIsect T = load_isect(S.tri_walk + i);
                     if (COUNT) n_tris++;
+                    steps++;
                     float t, u, v; bool inside;
                     const uint32_t fi = T.pad >> 1; // index in the figure order
                     if (tri_test_closer(T, o, d, cull_t, t, u, v, inside)) {
@@ -293,10 +303,12 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     bool active = false, overflow = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE; // fin: the lane's finished, unpublished path; bit 31 = it needs the exact role instead
     int sp = 0, k = 0;
+    uint32_t steps = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
+        if (P.group_cost) atomicAdd(&sh.cost[l >> 6], steps * PT_COST_LIGHT_STEP);
         if (overflow) { fin = l | 0x80000000u; return; }
         float v = 0.f;
         if (k == 1) v = __uint_as_float(stack[P8_STACK - 2][lane]);
@@ -350,7 +362,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = make_ray_inv(o, d);
-                    cur = 0; sp = 0; k = 0; overflow = false;
+                    cur = 0; sp = 0; k = 0; overflow = false; steps = 0;
                     active = true;
                 }
             }
@@ -366,6 +378,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
+                steps++;
                 float n0, n1;
                 bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
                 bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
@@ -383,6 +396,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 for (;;) {
                     bool last, robust;
                     if (COUNT) n_tris++;
+                    steps++;
                     float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust);
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
                         if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= P8_STACK) overflow = true;
@@ -522,6 +536,13 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
                 else nd = vndf_sample(rng, sn, pk.get3(PK_D), alpha);
                 pk.keep(rng, packed);
             }
+            // the record and entry addresses are formed again from the slot number after the sampling code (an opaque copy, so that the
+            // two 64-bit pointers do not sit in registers across it)
+            uint32_t slot_again = slot;
+            int depth_again = depth;
+            asm volatile("" : "+v"(slot_again), "+v"(depth_again));
+            r = wf_rec(W, slot_again);
+            e = wf_entry(W, slot_again, depth_again);
             F3 brdf;
             {
                 const F3 d = pk.get3(PK_D), bc = pk.get3(PK_BC);
@@ -535,6 +556,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
                 ended = true; pk.end(f3(e0.x, e0.y, e0.z), depth);
             } else {
                 e[1] = make_float4(brdf.x, brdf.y, brdf.z, dot(nd, sn));
+                asm volatile("" : "+v"(sn.x), "+v"(sn.y), "+v"(sn.z)); // the pdf terms start from the normal again: nothing derived from it for the sampling code (its rotation) waits in registers
                 float pdf = 0.f;                                                       // distributions.h:268-276, first two terms
                 pdf += cosine_pdf(sn, nd);
                 pdf += vndf_pdf(sn, nd, pk.get3(PK_D), alpha);
@@ -707,7 +729,7 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
             pt_push(sh, PT_Q_TRACE, got, next);
             pt_push(sh, PT_Q_LIGHT, got, with_light);
             pt_push(sh, PT_Q_XTRACE, got, got != PT_NONE && todo == PT_SHADE_EXACT);
-            if (got != PT_NONE && todo != PT_SHADE_EXACT) atomicAdd(&sh.cost[got >> 6], 1u);
+            if (got != PT_NONE && todo != PT_SHADE_EXACT) atomicAdd(&sh.cost[got >> 6], (uint32_t)PT_COST_SHADE);
             const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == WF_PARKED)); // finished, or parked for the next phase
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;

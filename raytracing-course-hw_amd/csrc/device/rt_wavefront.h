@@ -52,7 +52,7 @@ struct WfView {
 
 RT_DEV float4 *wf_rec(const WfView &W, uint32_t slot) { return W.r0 + (size_t)slot * W.stride; }
 #define WF_REC_BASE 4          // float4 in front of the per-level entries: q0..q3 (16 float4 = two 128-byte lines per path at depth 6)
-RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0 + (size_t)slot * W.stride + WF_REC_BASE + 2 * level; }
+RT_DEV float4 *wf_entry(const WfView &W, uint32_t slot, int level) { return W.r0 + ((size_t)slot * W.stride + (uint32_t)(WF_REC_BASE + 2 * level)); } // one 64-bit multiply-add of 32-bit operands
 
 #define WF_CTR 8               // counter words per round
 #ifndef WF_STACK

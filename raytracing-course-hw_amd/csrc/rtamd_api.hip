@@ -636,20 +636,58 @@ static std::vector<int> phase_stops(bool rebalance, int phase0, int samples, int
     return stops;
 }
 
-// Between the two phases of a persistent render: read the hits every workgroup shaded per 8x8 sub-tile in the first phase and deal the
-// sub-tiles again, longest processing time first onto the least loaded workgroup (at most groups_per_block each); the lists go to
-// d_ofs / d_ids for the second launch.
-static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_ofs, uint32_t *d_ids, uint32_t groups, uint32_t blocks, uint32_t groups_per_block, hipStream_t stream) {
+// Between the phases of a persistent render: read what every 8x8 sub-tile cost in the phase that just ended (PT_COST_*, rt_persistent.h)
+// and how long every workgroup ran, and deal the sub-tiles again — longest processing time first onto the workgroup that would be done
+// with it soonest (at most groups_per_block each); the lists go to d_ofs / d_ids for the next launch.
+// Workgroups are not equally fast.  The five that share a CU are served oldest wave first, so at equal load they leave staggered
+// (measured on the 1080p frame: 1,278 / 1,328 / 1,384 / 1,447 / 1,526 ms by launch order), and from the first exit on the CU runs with four
+// waves per SIMD, then three ...  So the deal is by speed: speed(b) = (cost of the sub-tiles b owned) / (its run time) in the phase that
+// just ended, and a sub-tile goes to the workgroup with the smallest load / speed.  `owner` (sub-tile -> workgroup of the phase that
+// just ended; empty = the kernel's round-robin deal) is updated to the new deal.  d_times: per workgroup {start, exit, -} in 100 MHz
+// ticks (PtParams::debug), nullable.
+static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_ofs, uint32_t *d_ids, uint32_t groups, uint32_t blocks, uint32_t groups_per_block, hipStream_t stream,
+                          const unsigned long long *d_times = nullptr, std::vector<uint32_t> *owner = nullptr) {
     std::vector<uint32_t> cost(groups), ofs, ids, order(groups);
     HIP_CHECK(hipStreamSynchronize(stream));
     const double t0 = now_ms();
     HIP_CHECK(hipMemcpy(cost.data(), d_cost, (size_t)groups * 4, hipMemcpyDeviceToHost));
+    std::vector<double> slowness(blocks, 1.0); // time per unit of cost, relative to the mean
+    if (d_times && owner && !getenv("RTAMD_PT_NO_SPEEDS")) {
+        std::vector<unsigned long long> times((size_t)blocks * 3);
+        HIP_CHECK(hipMemcpy(times.data(), d_times, times.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<double> had(blocks, 0.0);
+        for (uint32_t g = 0; g < groups; g++) had[owner->empty() ? g % blocks : (*owner)[g]] += (double)cost[g] + 1.0;
+        double sum = 0; uint32_t n = 0;
+        for (uint32_t b = 0; b < blocks; b++) {
+            const double dur = times[3 * b + 1] > times[3 * b] ? (double)(times[3 * b + 1] - times[3 * b]) : 0.0;
+            slowness[b] = dur > 0 && had[b] > 0 ? dur / had[b] : 0.0;
+            if (slowness[b] > 0) { sum += slowness[b]; n++; }
+        }
+        const double mean = n ? sum / n : 1.0;
+        // The workgroups are dispatched in index order, one round of n_cus after the other, so the age rank of a workgroup on its CU is
+        // its index / n_cus.  The measured slowness is split into the mean of the workgroup's round (the age effect: over-relaxed,
+        // because a slow workgroup ran its last stretch with its faster neighbours already gone, so the phase shows less of a
+        // difference than an even finish will: 1.5 measured best on the 1080p frame) and the
+        // workgroup's own deviation from it (half of which is gone in the next phase: damped).
+        const double gamma_round = getenv("RTAMD_PT_SPEED_GAMMA") ? atof(getenv("RTAMD_PT_SPEED_GAMMA")) : 1.5;
+        const double gamma_own = getenv("RTAMD_PT_SPEED_GAMMA_OWN") ? atof(getenv("RTAMD_PT_SPEED_GAMMA_OWN")) : 0.4;
+        const uint32_t round_size = scene->n_cus > 0 && blocks % (uint32_t)scene->n_cus == 0 ? (uint32_t)scene->n_cus : blocks;
+        for (uint32_t r0 = 0; r0 < blocks; r0 += round_size) {
+            double lsum = 0; uint32_t ln = 0;
+            for (uint32_t b = r0; b < r0 + round_size; b++) if (slowness[b] > 0) { lsum += log(slowness[b] / mean); ln++; }
+            const double lround = ln ? lsum / ln : 0.0;
+            for (uint32_t b = r0; b < r0 + round_size; b++) {
+                const double s = slowness[b] > 0 ? exp(gamma_round * lround + gamma_own * (log(slowness[b] / mean) - lround)) : exp(gamma_round * lround);
+                slowness[b] = s < 0.5 ? 0.5 : (s > 2.0 ? 2.0 : s); // a workgroup with almost nothing to do says little about its speed
+            }
+        }
+    }
     for (uint32_t g = 0; g < groups; g++) order[g] = g;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
-    std::vector<std::pair<uint64_t, uint32_t>> heap; // (load, block), min-heap
+    std::vector<std::pair<double, uint32_t>> heap; // (time at which the block is done with what it holds, block), min-heap
     heap.reserve(blocks);
-    for (uint32_t b = 0; b < blocks; b++) heap.push_back({0ull, b});
-    auto cmp = [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a > b; };
+    for (uint32_t b = 0; b < blocks; b++) heap.push_back({0.0, b});
+    auto cmp = [](const std::pair<double, uint32_t> &a, const std::pair<double, uint32_t> &b) { return a > b; };
     std::make_heap(heap.begin(), heap.end(), cmp);
     std::vector<std::vector<uint32_t>> mine(blocks);
     uint64_t total = 0, before_max = 0;
@@ -658,17 +696,29 @@ static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_o
         std::pop_heap(heap.begin(), heap.end(), cmp);
         auto &top = heap.back();
         mine[top.second].push_back(g);
-        top.first += (uint64_t)cost[g] + 1u; // + 1: empty sub-tiles (padding) are spread evenly too
+        top.first += ((double)cost[g] + 1.0) * slowness[top.second]; // + 1: empty sub-tiles (padding) are spread evenly too
         if (mine[top.second].size() >= groups_per_block) heap.pop_back(); // full: out of the deal
         else std::push_heap(heap.begin(), heap.end(), cmp);
     }
     ofs.assign(blocks + 1, 0);
+    if (owner) owner->assign(groups, 0);
     for (uint32_t b = 0; b < blocks; b++) {
         std::sort(mine[b].begin(), mine[b].end());
         ofs[b] = (uint32_t)ids.size();
         ids.insert(ids.end(), mine[b].begin(), mine[b].end());
+        if (owner) for (uint32_t g : mine[b]) (*owner)[g] = b;
     }
     ofs[blocks] = (uint32_t)ids.size();
+    if (const char *dump = getenv("RTAMD_DUMP_DEAL")) { // diagnostic: what the re-deal gave every workgroup (tools/tuning/wg_balance.py)
+        if (FILE *f = fopen(dump, "w")) {
+            for (uint32_t b = 0; b < blocks; b++) {
+                uint64_t load = 0;
+                for (uint32_t g : mine[b]) load += cost[g];
+                fprintf(f, "%u %zu %llu %.4f\n", b, mine[b].size(), (unsigned long long)load, slowness[b]);
+            }
+            fclose(f);
+        }
+    }
     HIP_CHECK(hipMemcpyAsync(d_ofs, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipStreamSynchronize(stream)); // the vectors go out of scope
@@ -719,11 +769,10 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     P.prio = getenv("RTAMD_PT_PRIO") ? atoi(getenv("RTAMD_PT_PRIO")) : 0;
     P.counters = scene->d_counters;
     P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
+    // every workgroup leaves its start and exit time (the re-deal measures the workgroups' speeds with them)
     P.debug = nullptr;
-    if (getenv("RTAMD_DEBUG_COUNTERS")) {
-        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
-        if (n_blocks_max <= PT_DEBUG_BLOCKS) P.debug = scene->d_pt_debug;
-    }
+    if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
+    if (n_blocks_max <= PT_DEBUG_BLOCKS) P.debug = scene->d_pt_debug;
     float4 *d_trace = nullptr;
     const uint32_t trace_cap = 1u << 16;
     if (count && getenv("RTAMD_TRACE_PIXEL") && getenv("RTAMD_TRACE_OUT")) { // diagnostic: tests/diagnostics/trace_pixel.py
@@ -746,6 +795,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     W.stride = (uint32_t)WF_REC_BASE + 2u * (uint32_t)scene->pt_levels;
     uint32_t first = 0, launch = 0;
     scene->pt_blocks = 0; scene->pt_rebalance_ms = 0; scene->pt_imbalance = 0;
+    std::vector<uint32_t> owner; // sub-tile -> workgroup of the phase in flight
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t groups = n_work - first < pass_groups ? n_work - first : pass_groups;
         W.n_slots = groups * 64u;
@@ -760,7 +810,8 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
             P.group_cost = ph + 1 < phases ? d_cost : nullptr;   // every phase but the last measures for the next re-deal
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
-            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
+            if (ph == 0) owner.clear(); // the kernel's round-robin deal
+            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream, P.debug, &owner);
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             // kernel variant by the features this render can reach (fewer features, fewer spilled registers): the hw7 integrator has no
@@ -1081,6 +1132,12 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                             100 * h_cnt[16] / tt, 100 * h_cnt[17] / tt, 100 * h_cnt[18] / tt, 100 * h_cnt[19] / tt, 100 * h_cnt[20] / tt,
                             (double)h_cnt[22] / (double)(h_cnt[21] ? h_cnt[21] : 1), h_cnt[21], (double)h_cnt[24] / (double)(h_cnt[23] ? h_cnt[23] : 1), h_cnt[23],
                             h_cnt[25], h_cnt[26], (double)h_cnt[27] / (double)(h_cnt[26] ? h_cnt[26] : 1));
+                }
+                if (const char *dump = getenv("RTAMD_DUMP_WG")) { // diagnostic: start / exit time (ms after the first start) and paths of every workgroup of the last launch
+                    if (FILE *f = fopen(dump, "w")) {
+                        for (uint32_t b = 0; b < scene->pt_blocks; b++) fprintf(f, "%u %.4f %.4f %llu\n", b, (dbg[3 * b] - t0) * 1e-5, (dbg[3 * b + 1] - t0) * 1e-5, dbg[3 * b + 2]);
+                        fclose(f);
+                    }
                 }
                 fprintf(stderr, "[rtamd] persistent pipeline: %u launches; re-deal of the sub-tiles took %.2f ms on the host (slowest workgroup / mean under the round-robin deal: %.3f)\n",
                         scene->pt_launches, scene->pt_rebalance_ms, scene->pt_imbalance);

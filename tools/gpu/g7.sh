@@ -1,0 +1,5 @@
+set -o pipefail
+mkdir -p gpurun_out
+RTAMD_DEBUG_COUNTERS=1 timeout -k 10 400 python tools/tuning/pt_probe.py --spp 256 --reps 1 "" "RTAMD_PT_SPEED_GAMMA=1.0" "RTAMD_PT_SPEED_GAMMA=1.5" "RTAMD_PT_SPEED_GAMMA=1.8" "RTAMD_PT_PHASES=3" "RTAMD_PT_PHASES=3 RTAMD_PT_SPEED_GAMMA=1.0" > gpurun_out/r3_probe7.log 2>&1; rc=$?
+grep -v "in-flight\|finished by\|amdgpu.ids" gpurun_out/r3_probe7.log | grep "exit times\|Msamples" | sed 's/; exact closest.*//'
+exit $rc

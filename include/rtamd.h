@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTAMD_ABI_VERSION 5
+#define RTAMD_ABI_VERSION 6
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -200,7 +200,11 @@ typedef struct rt_stats {
     uint32_t dominant_kernel_launches; /* launches of the dominant kernel (rt_stats.pipeline says which) */
     double dominant_kernel_ms;         /* sum of their HIP-event durations on the launch stream */
     uint32_t pipeline;                 /* rt_pipeline: how the kernels of this render were organised */
-    uint32_t reserved;
+    uint32_t reference_exact;          /* hw6 / hw7 / hw8 renders: 1 = every box decision of this render was the reference's own (the walkers'
+                                          hits went through the exactness gate, the doubtful ones through the reference-exact walk);
+                                          0 = the answer of the walkers' padded boxes stood (RTAMD_NO_EXACT_BOXES, RT_BUILD_DEVICE_BVH,
+                                          RTAMD_KERNEL=wavefront|mega, or a tree beyond the gated pipelines' limits): a pixel in ~1e5 may
+                                          then differ from the reference's.  0 for the other integrators (nothing to gate). */
     uint64_t exact_closest_hits, exact_light_sums; /* RT_PIPELINE_PERSISTENT: queries re-walked with the reference's own box
                                                       arithmetic (hw8/src/primitives.cpp:29-53,163-165) because the fast walk's
                                                       answer was not robust against it */

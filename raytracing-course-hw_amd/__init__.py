@@ -83,7 +83,7 @@ class rt_stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("total_ms", C.c_double), ("samples", C.c_uint64),
                 ("closest_hit_queries", C.c_uint64), ("light_pdf_queries", C.c_uint64), ("node_visits", C.c_uint64),
                 ("triangle_tests", C.c_uint64), ("launches", C.c_uint32), ("dominant_kernel_launches", C.c_uint32),
-                ("dominant_kernel_ms", C.c_double), ("pipeline", C.c_uint32), ("reserved", C.c_uint32),
+                ("dominant_kernel_ms", C.c_double), ("pipeline", C.c_uint32), ("reference_exact", C.c_uint32),
                 ("exact_closest_hits", C.c_uint64), ("exact_light_sums", C.c_uint64)]
 
 

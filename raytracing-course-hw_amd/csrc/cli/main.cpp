@@ -67,6 +67,8 @@ int main(int argc, const char *argv[]) {
         if (rt_scene_create(&desc, &scene) != RT_OK) return die();
         if (rt_render(scene, &p, nullptr, rgb8.data(), &st) != RT_OK) return die();
         fprintf(stderr, "render: %.3f ms on the GPU, %.2f Msamples/s\n", st.kernel_ms, st.samples / (st.kernel_ms * 1e3));
+        if ((p.integrator == RT_INTEGRATOR_HW8 || p.integrator == RT_INTEGRATOR_HW7 || p.integrator == RT_INTEGRATOR_HW6) && !st.reference_exact)
+            fprintf(stderr, "note: this render kept the answers of the walkers' padded boxes (no exactness gate on this path: see rt_stats.reference_exact in rtamd.h); about one pixel in 1e5 may differ from the reference's\n");
         rt_scene_destroy(scene);
     }
     if (rt_write_ppm(out_path, p.width, p.height, rgb8.data()) != RT_OK) return die();

@@ -121,6 +121,11 @@ RT_DEV float ref_light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack) 
     return v;
 }
 
+// The gate's own arithmetic is not replay arithmetic: it only has to err on the cautious side, and its thresholds carry 4x the rounding
+// bound they guard.  So its reciprocals are the hardware's v_rcp_f32 (1 ulp) instead of IEEE divisions (~10 instructions each): the
+// 2^-23 relative difference disappears in those margins.  Where a result is used as a floor or a ceiling it is nudged the safe way.
+RT_DEV float pt_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // Is the point P = o + t d, hit on a triangle whose box is [lo, hi], robustly inside that box — so robustly that the reference's
 // slab test accepts this box and every box containing it whatever the rounding?  The reference computes per axis the slab
 // interval [ta_j, tb_j] in t (monotonic: never inverted on one axis) and accepts when max_j ta_j <= min_k tb_k and that
@@ -130,7 +135,7 @@ RT_DEV float ref_light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack) 
 // is sufficient, and t + b_k >= c1 t keeps the exit in front of the origin.  Boxes only grow towards the root, which only
 // increases a_j and b_k.  A flat box (a_j = b_j = 0 on its axis) passes as long as the other axes have room.
 RT_DEV bool pt_box_robust(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
-    const float ix = 1.0f / fmaxf(fabsf(d.x), 1e-30f), iy = 1.0f / fmaxf(fabsf(d.y), 1e-30f), iz = 1.0f / fmaxf(fabsf(d.z), 1e-30f);
+    const float ix = pt_rcp(fmaxf(fabsf(d.x), 1e-30f)), iy = pt_rcp(fmaxf(fabsf(d.y), 1e-30f)), iz = pt_rcp(fmaxf(fabsf(d.z), 1e-30f));
     const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
     const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
     const float inz = d.z > 0 ? P.z - lo.z : hi.z - P.z, outz = d.z > 0 ? hi.z - P.z : P.z - lo.z;
@@ -158,7 +163,7 @@ RT_DEV bool pt_box_robust(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
 // The runner-up's distance behind the hit travels in six bits of the hit word: code c > 0 means (t2 - t) / t >= 2^(c - 41),
 // c = 0 means "no farther than 2^-40 t" (or equal); the gate works with that floor (at most 2x too cautious).
 RT_DEV uint32_t pt_gap_code(float t, float t2) {
-    const float r = (t2 - t) / t;
+    const float r = (t2 - t) * pt_rcp(t) * 0.99999976f; // a floor: two ulp down covers the reciprocal's error
     if (!(r > 0.f)) return 0u;
     const int c = (int)(__float_as_uint(r) >> 23) - 127 + 41;
     return (uint32_t)(c < 0 ? 0 : (c > 63 ? 63 : c)) << WF_GAP_SHIFT;
@@ -170,14 +175,14 @@ RT_DEV float pt_gap_floor(uint32_t hit, float t) {
 // Absolute part of the walkers' look-behind: the window of a hit that lies inside its box (in_k >= 0) is at most c1 t + c2 max_k 1/|d_k|.
 // c2x = 1.25f * c2, formed on the host (SceneView::box_c2x): a uniform float product would otherwise sit in a VGPR for the whole launch.
 RT_DEV float pt_look_behind_abs(F3 d, float c2x) {
-    return c2x / fmaxf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), 1e-30f);
+    return 1.0000005f * c2x * pt_rcp(fmaxf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), 1e-30f)); // a ceiling (the gate's `seen` repeats it a hair smaller)
 }
 // The gate: does the walkers' hit (t, runner-up at t2) stand as the reference's answer?  Yes when every box above it passes the
 // reference's test robustly (pt_box_robust), the runner-up lies beyond the hit's window and beyond the tie tolerance, and the window
 // does not reach past what the walkers looked at (a hit reported well in front of its own box).
 RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2, float c2x, float cull_k) {
     const F3 P = o + t * d;
-    const float ix = 1.0f / fmaxf(fabsf(d.x), 1e-30f), iy = 1.0f / fmaxf(fabsf(d.y), 1e-30f), iz = 1.0f / fmaxf(fabsf(d.z), 1e-30f);
+    const float ix = pt_rcp(fmaxf(fabsf(d.x), 1e-30f)), iy = pt_rcp(fmaxf(fabsf(d.y), 1e-30f)), iz = pt_rcp(fmaxf(fabsf(d.z), 1e-30f));
     const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
     const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
     const float inz = d.z > 0 ? P.z - lo.z : hi.z - P.z, outz = d.z > 0 ? hi.z - P.z : P.z - lo.z;
@@ -187,7 +192,7 @@ RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2
     const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
     const float exit_ = t + fminf(fminf(bx, by), bz);
     const float window = need - fminf(fminf(ax, ay), az);
-    const float seen = fmaxf(cull_k * t, c2x * fmaxf(fmaxf(ix, iy), iz));   // the walkers' look-behind for this ray and t
+    const float seen = fmaxf(cull_k * t, 0.9999995f * c2x * fmaxf(fmaxf(ix, iy), iz));   // the walkers' look-behind for this ray and t, as a floor
     return worst >= need && exit_ >= need && gap > window && gap > 4.8e-7f * (t + gap) && window <= seen; // NaN compares false: exact walk
 }
 

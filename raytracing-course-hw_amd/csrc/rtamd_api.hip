@@ -15,6 +15,7 @@
 #include "host/host_scene.h"
 #include "host/png.h"
 #include "host/scene_prep.h"
+#include "host/shared_prep.h"
 #include "host/hip_check.h"
 #include "host/device_build.h"
 #include "device/rt_kernels_hw8.h"
@@ -133,7 +134,14 @@ extern "C" {
 int rt_abi_version(void) { return RTAMD_ABI_VERSION; }
 const char *rt_last_error(void) { return g_last_error.c_str(); }
 
-int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) { return rtamd::scene_create_shared(desc, out, nullptr); }
+
+} // extern "C"
+
+// rt_scene_create with the host-side preparation of an hw8 / hw7 scene (the replay of the reference's figure and light order:
+// ~0.4 s for the benchmark scene) optionally taken from `shared`: the first caller fills it, the others wait for it and only upload.
+// rt_multi_create gives all its devices the same one (rtamd_multi.hip); the plain C entry point passes none.
+int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd::SharedPrep *shared) {
     if (!desc || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
     if (desc->struct_size != sizeof(rt_scene_desc)) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: struct_size mismatch (ABI skew)");
     *out = nullptr;
@@ -314,8 +322,12 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         // which carries its figure index (RTAMD_HOST_BVH=1, or a handful of triangles: the walkers use the reference topology).
         const bool fast_build = (desc->build_flags & RT_BUILD_DEVICE_BVH) && desc->n_triangles >= 64;
         const bool walk_tree_on_device = desc->n_triangles >= 64 && (fast_build || !getenv("RTAMD_HOST_BVH"));
-        PreparedScene P;
-        prepare_scene(*desc, P, fast_build);
+        PreparedScene P_local;
+        if (shared) std::call_once(shared->once, [&] { try { prepare_scene(*desc, shared->P, fast_build); } catch (...) { shared->error = std::current_exception(); } });
+        else prepare_scene(*desc, P_local, fast_build);
+        if (shared && shared->error) std::rethrow_exception(shared->error);
+        const PreparedScene &P = shared ? shared->P : P_local; // read-only from here on (several devices may be uploading from it)
+        uint32_t bvh_depth = P.bvh_depth, n_nodes = (uint32_t)P.nodes.size();
         double t1 = now_ms();
         uint64_t bytes = 0;
         SceneView &V = s->view;
@@ -346,8 +358,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             (void)hipFree(t.order); (void)hipFree(t.last); t.order = nullptr; t.last = nullptr;
             V.nodes = keep(t.nodes); V.tri_walk = keep(d_walk);
             bytes += (uint64_t)t.n_nodes * sizeof(GpuNode) + (uint64_t)n * sizeof(TriIsect);
-            P.bvh_depth = t.depth;
-            P.nodes.resize(t.n_nodes);
+            bvh_depth = t.depth;
+            n_nodes = t.n_nodes;
             s->info.bvh_build_ms = t.build_ms; s->info.bvh_on_device = 1;
             s->device_tree = fast_build;
         } else {
@@ -356,8 +368,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         }
         if (ref_depth > RT_STACK_SIZE - 2) // the exact walks keep a private stack over the reference's own tree
             return fail(RT_ERR_LIMIT, "the reference's scene BVH is deeper than the exact walk's stack (" + std::to_string(ref_depth) + ")");
-        if (P.bvh_depth > RT_STACK_SIZE - 2 || P.light_bvh_depth > RT_STACK_SIZE - 2)
-            return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P.bvh_depth) + "/" +
+        if (bvh_depth > RT_STACK_SIZE - 2 || P.light_bvh_depth > RT_STACK_SIZE - 2)
+            return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(bvh_depth) + "/" +
                                           std::to_string(P.light_bvh_depth) + ")");
         V.light_nodes = keep(upload(P.light_nodes, bytes));
         V.light_sep = keep(upload(P.light_sep, bytes));
@@ -374,7 +386,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         std::vector<float> lut(P.srgb_lut, P.srgb_lut + 256);
         V.srgb_lut = keep(upload(lut, bytes));
         V.n_tris = desc->n_triangles;
-        V.n_nodes = (uint32_t)P.nodes.size();
+        V.n_nodes = n_nodes;
         V.n_lights = (uint32_t)P.lights.size();
         V.n_components = P.lights.empty() ? 2u : 3u; // scene.cpp:65-74
         V.last_level_emission_only = 1;
@@ -403,9 +415,9 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         s->light_order = P.light_order;
         s->info.n_triangles = desc->n_triangles;
         s->info.n_lights = V.n_lights;
-        s->info.n_bvh_nodes = (uint32_t)P.nodes.size();
+        s->info.n_bvh_nodes = n_nodes;
         s->info.n_light_bvh_nodes = (uint32_t)P.light_nodes.size();
-        s->info.bvh_depth = P.bvh_depth;
+        s->info.bvh_depth = bvh_depth;
         s->info.light_bvh_depth = P.light_bvh_depth;
         s->info.device_bytes = bytes;
         s->info.prep_ms = t1 - t0;
@@ -418,6 +430,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         return fail(RT_ERR_INVALID_ARG, e.what());
     }
 }
+
+extern "C" {
 
 void rt_scene_destroy(rt_scene *scene) { delete scene; }
 
@@ -1012,7 +1026,12 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (scene->flavor == RT_INTEGRATOR_HW6 && R.ray_depth > RT6_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw6 ray_depth above 8");
         SceneView V8 = scene->view; // per-render copy: the hw7 replay switches are render parameters, not scene state
         if (hw7) { V8.hw7 = 1; V8.last_level_emission_only = 0; V8.env_image = -1; }
-        if (!use_persistent && !getenv("RTAMD_ROUNDS_EXACT")) V8.exact_boxes = 0; // round pipeline and megakernel: the padded box test's answer stands
+        // Exactness follows the scene, not the pipeline: when the persistent pipeline cannot take the scene (a tree deeper than its
+        // stack columns), the round pipeline runs with its exact kernels on.  Only an explicit RTAMD_KERNEL=wavefront (the yardstick
+        // of the benchmarks; RTAMD_ROUNDS_EXACT=1 switches the exact kernels on there too) and the megakernel, which has no gate,
+        // keep the padded boxes' answer — and say so in rt_stats.reference_exact.
+        const bool rounds_chosen = ksel && strcmp(ksel, "wavefront") == 0;
+        if (!use_persistent && (!use_wavefront || (rounds_chosen && !getenv("RTAMD_ROUNDS_EXACT")))) V8.exact_boxes = 0;
         if (!V8.exact_boxes) V8.cull_k = 4.8e-7f; // no exact walks to feed: the walkers look behind the best hit by the tie tolerance only
         uint32_t launches = 0;
         bool time_trace = false, use_persistent6 = false;
@@ -1176,6 +1195,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
             stats->pipeline = (uint32_t)scene->pipeline;
+            stats->reference_exact = use_persistent6 ? (scene->view6.exact_boxes ? 1u : 0u)
+                                     : ((scene->flavor == RT_INTEGRATOR_HW8 && (use_persistent || (use_wavefront && blocks)) && V8.exact_boxes) ? 1u : 0u);
             if (use_persistent || use_persistent6) {
                 double sum = 0;
                 for (uint32_t pp = 0; time_trace && pp < scene->pt_launches; pp++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * pp], scene->ev_pool[2 * pp + 1])); sum += e; }

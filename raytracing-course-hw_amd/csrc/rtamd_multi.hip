@@ -1,7 +1,10 @@
 // Multi-GPU render under the C-ABI (include/rtamd.h: rt_multi_*): one process, one rt_scene per HIP device, one host thread
 // per device, the frame's 32x32 tiles dealt round-robin to the devices (the per-pixel seed y*W+x is global, so any deal gives
-// the reference's pixels: hw8/src/sceneio.cpp:389-391), and ONE exchange step: every device's compact shard buffer goes to
-// device 0 with hipMemcpyPeerAsync (xGMI, each sender over its own link) where a small kernel scatters the tiles into the frame.
+// the reference's pixels: hw8/src/sceneio.cpp:389-391), and ONE exchange step: every device PUSHES its compact shard buffer to its
+// landing area on device 0 (hipMemcpyPeerAsync on the sender's own stream, straight after its render: each sender over its own xGMI
+// link, in the direction peer access was enabled for, overlapping the slower shards' renders) and records an event; device 0's
+// stream waits for each event and scatters that shard's tiles into the frame.  The host-side preparation of the scene (the replay of
+// the reference's figure order) runs once and is shared by the devices' scenes (host/shared_prep.h).
 // This is what `./run.sh scene.gltf W H SPP out.ppm` (csrc/cli/main.cpp) uses when more than one GPU is visible; the
 // reference seam is the pixel loop of sceneio::renderScene driven from main (hw8/src/main.cpp:7-18).
 #include <hip/hip_runtime.h>
@@ -12,6 +15,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/rtamd.h"
+#include "host/shared_prep.h"
 
 namespace rtamd { void set_error(const std::string &msg); }
 
@@ -42,7 +46,7 @@ struct DeviceSlot {
     float *d_rgb = nullptr;       // this device's shard, float
     uint8_t *d_rgb8 = nullptr;    // this device's shard, u8
     size_t cap_rgb = 0, cap_rgb8 = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;    // recorded on `stream` after this device's shard has landed on device 0
 };
 
 } // namespace
@@ -103,7 +107,9 @@ int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices
     *out = nullptr;
     const int visible = rt_device_count();
     if (visible == 0) return fail(RT_ERR_NO_DEVICE, "rt_multi_create: no HIP device available (this library has no CPU fallback)");
+    try {
     std::unique_ptr<rt_multi> m(new rt_multi());
+    rtamd::SharedPrep prep; // one host-side preparation for all devices
     m->dev.resize((size_t)n_devices);
     for (int i = 0; i < n_devices; i++) {
         m->dev[i].device = devices ? devices[i] : i;
@@ -116,7 +122,7 @@ int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices
     for (int i = 0; i < n_devices; i++)
         th.emplace_back([&, i] {
             if (hipSetDevice(m->dev[i].device) != hipSuccess) { rc[i] = RT_ERR_HIP; err[i] = "hipSetDevice failed"; return; }
-            rc[i] = rt_scene_create(desc, &m->dev[i].scene);
+            rc[i] = rtamd::scene_create_shared(desc, &m->dev[i].scene, &prep);
             if (rc[i] != RT_OK) { err[i] = rt_last_error(); return; }
             if (hipStreamCreateWithFlags(&m->dev[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->dev[i].done, hipEventDisableTiming) != hipSuccess) {
                 rc[i] = RT_ERR_HIP; err[i] = "stream / event creation failed";
@@ -125,7 +131,8 @@ int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices
     for (auto &t : th) t.join();
     for (int i = 0; i < n_devices; i++)
         if (rc[i] != RT_OK) return fail(rc[i], "rt_multi_create: device " + std::to_string(m->dev[i].device) + ": " + err[i]);
-    // peer access towards device 0 where the hardware offers it (hipMemcpyPeerAsync stages through the host otherwise)
+    // peer access from every sender towards device 0 — the direction of its push — where the hardware offers it (hipMemcpyPeerAsync
+    // stages through the host otherwise)
     for (int i = 1; i < n_devices; i++) {
         if (m->dev[i].device == m->dev[0].device) continue;
         int can = 0;
@@ -140,6 +147,11 @@ int rt_multi_create(const rt_scene_desc *desc, const int *devices, int n_devices
     m->land_cap_rgb.assign((size_t)n_devices, 0); m->land_cap_rgb8.assign((size_t)n_devices, 0);
     *out = m.release();
     return RT_OK;
+    } catch (const std::exception &e) { // std::bad_alloc, std::system_error of a thread: nothing may cross the C boundary
+        return fail(RT_ERR_INVALID_ARG, std::string("rt_multi_create: ") + e.what());
+    } catch (...) {
+        return fail(RT_ERR_INVALID_ARG, "rt_multi_create: unknown exception");
+    }
 }
 
 void rt_multi_destroy(rt_multi *m) { delete m; }
@@ -165,7 +177,24 @@ int rt_multi_render(rt_multi *m, const rt_render_params *params, float *out_rgb,
         if (elems[i] == 0 && params->width > 0 && params->height > 0 && N == 1) return fail(RT_ERR_INVALID_ARG, "rt_multi_render: bad render parameters");
     }
     if (params->width <= 0 || params->height <= 0 || params->samples <= 0) return fail(RT_ERR_INVALID_ARG, "rt_multi_render: width, height and samples must be positive");
-    // every device renders its shard from its own host thread
+    try {
+    // landing areas on device 0 and the frame, before any thread starts (allocations on device 0 from this thread only)
+    const int dev0 = m->dev[0].device;
+    MHIP(hipSetDevice(dev0));
+    hipStream_t s0 = m->dev[0].stream;
+    const size_t frame_elems = (size_t)params->width * params->height * 3;
+    float *frame_rgb = nullptr;
+    uint8_t *frame_rgb8 = nullptr;
+    if (N > 1) {
+        if (out_rgb) { if (out_dev) frame_rgb = out_rgb; else { int r = grow(m->frame_rgb, m->frame_cap_rgb, frame_elems); if (r != RT_OK) return r; frame_rgb = m->frame_rgb; } }
+        if (out_rgb8) { if (out_dev) frame_rgb8 = out_rgb8; else { int r = grow(m->frame_rgb8, m->frame_cap_rgb8, frame_elems); if (r != RT_OK) return r; frame_rgb8 = m->frame_rgb8; } }
+        for (int i = 1; i < N; i++) {
+            if (elems[i] == 0) continue;
+            if (out_rgb) { int r = grow(m->land_rgb[i], m->land_cap_rgb[i], elems[i]); if (r != RT_OK) return r; }
+            if (out_rgb8) { int r = grow(m->land_rgb8[i], m->land_cap_rgb8[i], elems[i]); if (r != RT_OK) return r; }
+        }
+    }
+    // every device renders its shard from its own host thread and pushes it to device 0 as soon as it is done
     std::vector<int> rc((size_t)N, RT_OK);
     std::vector<std::string> err((size_t)N);
     std::vector<rt_stats> st((size_t)N);
@@ -178,41 +207,30 @@ int rt_multi_render(rt_multi *m, const rt_render_params *params, float *out_rgb,
             if (out_rgb && (rc[i] = grow(d.d_rgb, d.cap_rgb, elems[i])) != RT_OK) { err[i] = rt_last_error(); return; }
             if (out_rgb8 && (rc[i] = grow(d.d_rgb8, d.cap_rgb8, elems[i])) != RT_OK) { err[i] = rt_last_error(); return; }
             rc[i] = rt_render(d.scene, &p[i], out_rgb ? d.d_rgb : nullptr, out_rgb8 ? d.d_rgb8 : nullptr, &st[i]);
-            if (rc[i] != RT_OK) err[i] = rt_last_error();
+            if (rc[i] != RT_OK) { err[i] = rt_last_error(); return; }
+            if (i > 0 && N > 1) { // the push: this device's stream, this device's link
+                hipError_t e = hipSuccess;
+                if (out_rgb) e = hipMemcpyPeerAsync(m->land_rgb[i], dev0, d.d_rgb, d.device, elems[i] * sizeof(float), d.stream);
+                if (e == hipSuccess && out_rgb8) e = hipMemcpyPeerAsync(m->land_rgb8[i], dev0, d.d_rgb8, d.device, elems[i], d.stream);
+                if (e == hipSuccess) e = hipEventRecord(d.done, d.stream);
+                if (e != hipSuccess) { rc[i] = RT_ERR_HIP; err[i] = std::string("shard push: ") + hipGetErrorString(e); }
+            }
         });
     for (auto &t : th) t.join();
     for (int i = 0; i < N; i++)
         if (rc[i] != RT_OK) return fail(rc[i], "rt_multi_render: device " + std::to_string(m->dev[i].device) + ": " + err[i]);
-    // the one exchange step: shards -> device 0 (peer copies), tiles -> frame (kernel on device 0)
-    const int dev0 = m->dev[0].device;
+    // tiles -> frame on device 0, each shard as soon as its push has landed
     MHIP(hipSetDevice(dev0));
-    hipStream_t s0 = m->dev[0].stream;
-    const size_t frame_elems = (size_t)params->width * params->height * 3;
-    float *frame_rgb = nullptr;
-    uint8_t *frame_rgb8 = nullptr;
     if (N == 1) { frame_rgb = m->dev[0].d_rgb; frame_rgb8 = m->dev[0].d_rgb8; }
     else {
-        if (out_rgb) { if (out_dev) frame_rgb = out_rgb; else { int r = grow(m->frame_rgb, m->frame_cap_rgb, frame_elems); if (r != RT_OK) return r; frame_rgb = m->frame_rgb; } }
-        if (out_rgb8) { if (out_dev) frame_rgb8 = out_rgb8; else { int r = grow(m->frame_rgb8, m->frame_cap_rgb8, frame_elems); if (r != RT_OK) return r; frame_rgb8 = m->frame_rgb8; } }
         const int tiles_x = (params->width + tile - 1) / tile, tiles_y = (params->height + tile - 1) / tile;
         const uint32_t total_tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
         for (int i = 0; i < N; i++) {
             if (elems[i] == 0) continue;
             const uint32_t n_tiles = (total_tiles - (uint32_t)i + (uint32_t)N - 1) / (uint32_t)N;
-            const float *src_rgb = m->dev[i].d_rgb;
-            const uint8_t *src_rgb8 = m->dev[i].d_rgb8;
-            if (i > 0) { // land the shard on device 0
-                if (out_rgb) {
-                    int r = grow(m->land_rgb[i], m->land_cap_rgb[i], elems[i]); if (r != RT_OK) return r;
-                    MHIP(hipMemcpyPeerAsync(m->land_rgb[i], dev0, m->dev[i].d_rgb, m->dev[i].device, elems[i] * sizeof(float), s0));
-                    src_rgb = m->land_rgb[i];
-                }
-                if (out_rgb8) {
-                    int r = grow(m->land_rgb8[i], m->land_cap_rgb8[i], elems[i]); if (r != RT_OK) return r;
-                    MHIP(hipMemcpyPeerAsync(m->land_rgb8[i], dev0, m->dev[i].d_rgb8, m->dev[i].device, elems[i], s0));
-                    src_rgb8 = m->land_rgb8[i];
-                }
-            }
+            const float *src_rgb = i ? m->land_rgb[i] : m->dev[0].d_rgb;
+            const uint8_t *src_rgb8 = i ? m->land_rgb8[i] : m->dev[0].d_rgb8;
+            if (i > 0) MHIP(hipStreamWaitEvent(s0, m->dev[i].done, 0));
             const unsigned blocks = (unsigned)((elems[i] + 255) / 256 < 65535 ? (elems[i] + 255) / 256 : 65535);
             if (out_rgb) hipLaunchKernelGGL(assemble_tiles_kernel<float>, dim3(blocks), dim3(256), 0, s0, src_rgb, frame_rgb, params->width, params->height, tile, tiles_x, i, N, n_tiles);
             if (out_rgb8) hipLaunchKernelGGL(assemble_tiles_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s0, src_rgb8, frame_rgb8, params->width, params->height, tile, tiles_x, i, N, n_tiles);
@@ -243,6 +261,11 @@ int rt_multi_render(rt_multi *m, const rt_render_params *params, float *out_rgb,
         stats->total_ms = now_ms() - t0; // host wall time of the whole call: renders, exchange, read-back
     }
     return RT_OK;
+    } catch (const std::exception &e) { // std::bad_alloc, std::system_error of a thread: nothing may cross the C boundary
+        return fail(RT_ERR_INVALID_ARG, std::string("rt_multi_render: ") + e.what());
+    } catch (...) {
+        return fail(RT_ERR_INVALID_ARG, "rt_multi_render: unknown exception");
+    }
 }
 
 } // extern "C"

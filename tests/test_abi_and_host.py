@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol(rt):
     assert declared == set(rt.ABI_SYMBOLS), declared ^ set(rt.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(rt.lib, name), f"librtamd.so does not export {name}"
-    assert rt.lib.rt_abi_version() == 5
+    assert rt.lib.rt_abi_version() == 6
 
 
 def test_struct_sizes_match_header(rt):

@@ -68,7 +68,7 @@ def test_hw8_closest_hits_do_not_depend_on_the_tree(rt, monkeypatch, n):
     ref, _, _ = oracle_lib.Hw8Oracle(sd).render(w, h, spp)
     differing = int(np.any(a != ref, axis=2).sum())
     print(f"    pixels differing from the oracle: {differing} of {w * h}")
-    assert differing <= 2
+    assert differing <= 2   # RTAMD_NO_EXACT_BOXES=1 above: without the exactness gate the padded boxes' answer stands (the known box-rounding class)
 
 
 @pytest.mark.parametrize("case", ["sphere", "soup_with_ties"])

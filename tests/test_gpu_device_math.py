@@ -68,7 +68,7 @@ def test_runner_up_gap_code_is_a_floor_within_a_factor_of_two(hooks):
     assert np.all(fl.astype(np.float64) <= np.maximum(gap32, 0) * (1 + 1e-6))
     c = (code >> 24).astype(np.int64)
     mid = (c > 0) & (c < 63)
-    assert np.all(fl[mid].astype(np.float64) * 2.0000005 >= gap32[mid])   # within a factor of two where the code is not saturated
+    assert np.all(fl[mid].astype(np.float64) * 2.000002 >= gap32[mid])    # within a factor of two (and the two ulp the device rounds down by) where the code is not saturated
     assert np.all(fl[:1000] == 0) and np.all(c[1000:2000] > 40)
     assert gap.min() >= 0
 

@@ -43,8 +43,8 @@ def _check(rt, sd, w, h, spp, depth=0, tag=""):
         rmse = float(np.sqrt(np.nanmean((rgb.astype(np.float64) - ref) ** 2)))
         print(f"{tag}[{kernel}] {w}x{h}x{spp} depth {depth or 6}: bit_exact {ok} rmse {rmse:.2e} nan_px {int(np.isnan(ref).any(axis=2).sum())}")
         assert np.array_equal(np.isnan(rgb), np.isnan(ref))
-        assert rmse < 1e-3
-        assert (rgb8 != ref8).sum() <= 3
+        if kernel == "persistent": assert ok and np.array_equal(rgb8, ref8)   # the gated default: bit for bit
+        else: assert rmse < 1e-3 and (rgb8 != ref8).sum() <= 3                # wavefront / mega: the padded boxes' answer, north_star tolerance
     os.environ.pop("RTAMD_KERNEL", None)
 
 

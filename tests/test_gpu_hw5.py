@@ -33,7 +33,7 @@ def test_hw5_matches_the_reference_radiance(rt, name):
     md5_ok = hashlib.md5(_ppm(w, h, rgb8)).hexdigest() == bytes(gold[name + "_md5"]).decode()
     print(f"hw5 {name}: rmse {rmse:.3e}, {nbad} of {w * h} pixels differ in any bit, PPM md5 equal to the program's: {md5_ok}")
     assert ref.mean() > 0.01 and rmse < RMSE_TOL
-    assert nbad <= 2
+    assert nbad == 0 and md5_ok   # the reference program's own floats and its PPM, bit for bit (the 80-bit `t + eps` stand-in has never shown)
     scene.close()
 
 
@@ -56,7 +56,7 @@ def test_hw5_larger_frame_against_oracle_and_sharded(rt):
     ref, _ = oracle_lib.Hw5Oracle(sd).render(w, h, spp, depth)
     rmse = float(np.sqrt(np.mean((rgb.astype(np.float64) - ref) ** 2)))
     print(f"hw5 200x150x16: rmse {rmse:.3e} bit_exact {np.array_equal(rgb, ref)}; {w * h * spp / st.kernel_ms / 1e3:.1f} Msamples/s")
-    assert rmse < RMSE_TOL
+    assert np.array_equal(rgb, ref)
     full = np.zeros_like(rgb)
     for k in range(2):
         buf, _, _ = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW5, ray_depth=depth, shard_index=k, shard_count=2, want_rgb8=False)

@@ -29,7 +29,8 @@ def test_hw7_matches_the_reference_radiance(rt, monkeypatch, name, kernel):
     rmse = float(np.sqrt(np.mean((rgb.astype(np.float64) - ref) ** 2)))
     nbad = int((rgb.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
     print(f"hw7 {name} [{kernel}]: rmse {rmse:.3e}, {nbad} of {w * h} pixels differ in any bit, byte mismatches {(rgb8 != ref8).sum()}")
-    assert ref.mean() > 0.01 and rmse < RMSE_TOL and nbad <= 2
+    assert ref.mean() > 0.01 and rmse < RMSE_TOL and nbad <= (0 if kernel == "persistent" else 2)  # the gated default: the reference's own floats, bit for bit
+    if kernel == "persistent": assert np.array_equal(rgb8, ref8)
     scene.close()
 
 
@@ -71,5 +72,5 @@ def test_headline_size_frame_against_the_reference_itself(rt, tmp_path):
         bad = int((np.abs(crop.astype(np.float64) - ref).max(axis=2) > 1e-3).sum())
         print(f"  crop ({x0},{y0}) vs the reference: rmse {rmse:.3e}, pixels off by > 1e-3: {bad}, bit_exact {np.array_equal(crop, ref)}")
         worst, desync = max(worst, rmse), desync + bad
-        assert ref.mean() > 0.01 and rmse < RMSE_TOL
+        assert ref.mean() > 0.01 and np.array_equal(crop, ref)   # against the reference's own compiled integrator, bit for bit
     scene.close()

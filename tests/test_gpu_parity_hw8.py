@@ -30,9 +30,10 @@ def test_sphere_emissive_matches_oracle(rt, sphere_scene, kernel, size, spp):
     rmse = _rmse(rgb, ref)
     bad = int((np.abs(rgb - ref).max(axis=2) > 1e-3).sum())
     print(f"{w}x{h}x{spp}: rmse {rmse:.3e}, desync pixels {bad}, byte mismatches {(rgb8 != ref8).sum()}, exact {np.array_equal(rgb, ref)}")
-    assert rmse < RMSE_TOL
-    assert bad <= max(1, (w * h) // 2000)
-    assert (rgb8 != ref8).sum() <= max(3, (w * h * 3) // 1000)
+    if kernel == "persistent":  # the default pipeline's claim: the reference's pixels bit for bit (exactness gate on)
+        assert st.reference_exact == 1 and np.array_equal(rgb, ref) and np.array_equal(rgb8, ref8)
+    else:                       # wavefront / mega keep the walkers' padded-box answer: north_star tolerance
+        assert st.reference_exact == 0 and rmse < RMSE_TOL and bad <= 1 and (rgb8 != ref8).sum() <= 3
     scene.close()
 
 

@@ -535,7 +535,7 @@ RT_DEV float vndf_pdf(F3 n, F3 d, F3 v, float alpha) { // :239-245
     return vndf_pdf_local(qtransform(q, d), qtransform(q, v), alpha);
 }
 RT_DEV F3 light_sample(const SceneView &S, Rng &rng, F3 x) { // :117-120, :81-94
-    int k = (int)(rng_u01(rng) * (float)S.n_lights);
+    int k = (int)(rng_u01(rng) * S.n_lights_f);
     const LightRec *L = S.lights + k;
     const float4 *q = reinterpret_cast<const float4 *>(L);
     float4 a4 = q[0], q0 = q[3], q1 = q[4];

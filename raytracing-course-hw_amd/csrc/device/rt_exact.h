@@ -175,7 +175,7 @@ RT_DEV float pt_gap_floor(uint32_t hit, float t) {
 // Absolute part of the walkers' look-behind: the window of a hit that lies inside its box (in_k >= 0) is at most c1 t + c2 max_k 1/|d_k|.
 // c2x = 1.25f * c2, formed on the host (SceneView::box_c2x): a uniform float product would otherwise sit in a VGPR for the whole launch.
 RT_DEV float pt_look_behind_abs(F3 d, float c2x) {
-    return 1.0000005f * c2x * pt_rcp(fmaxf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), 1e-30f)); // a ceiling (the gate's `seen` repeats it a hair smaller)
+    return c2x * (1.0000005f * pt_rcp(fmaxf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), 1e-30f))); // a ceiling (the gate's `seen` repeats it a hair smaller)
 }
 // The gate: does the walkers' hit (t, runner-up at t2) stand as the reference's answer?  Yes when every box above it passes the
 // reference's test robustly (pt_box_robust), the runner-up lies beyond the hit's window and beyond the tie tolerance, and the window
@@ -192,7 +192,7 @@ RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2
     const float worst = fminf(fminf(fminf(ax + by, ax + bz), fminf(ay + bx, ay + bz)), fminf(az + bx, az + by));
     const float exit_ = t + fminf(fminf(bx, by), bz);
     const float window = need - fminf(fminf(ax, ay), az);
-    const float seen = fmaxf(cull_k * t, 0.9999995f * c2x * fmaxf(fmaxf(ix, iy), iz));   // the walkers' look-behind for this ray and t, as a floor
+    const float seen = fmaxf(cull_k * t, c2x * (0.9999995f * fmaxf(fmaxf(ix, iy), iz)));   // the walkers' look-behind for this ray and t, as a floor
     return worst >= need && exit_ >= need && gap > window && gap > 4.8e-7f * (t + gap) && window <= seen; // NaN compares false: exact walk
 }
 

@@ -118,7 +118,9 @@ RT_DEV Hit6 closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack) {
 }
 
 // FiguresMix::getTotalPdf for triangle lights (hw6/src/include/distributions.h:212-256), reference addition tree.
-RT_DEV float light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
+// `stack`: anything indexable that holds RT6_STACK_SIZE words (a private array here; a strided slice of LDS in rt_persistent_hw6.h).
+template <class A>
+RT_DEV float light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, A stack) {
     RayInv ray = make_ray_inv(x, d);
     int sp = 0;
     unsigned long long mask_lo = 0, mask_hi = 0; // frame kind per stack slot: 1 = ADD(partial sum), 0 = TODO(child)
@@ -315,11 +317,11 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
             Frame6 &f = frames[fp];
             if (kind == RT_MAT_DIFFUSE) {
                 F3 xo = x + epsf * norma;
-                int comp = (int)(rng_u01(rng) * (float)S.n_components);                         // distributions.h:284
+                int comp = (int)(rng_u01(rng) * S.n_components_f);                         // distributions.h:284
                 F3 nd;
                 if (comp == 0) nd = cosine_sample(rng, norma);
                 else {                                                                          // :199-208, :129-141
-                    int li = (int)(rng_u01(rng) * (float)S.n_lights);
+                    int li = (int)(rng_u01(rng) * S.n_lights_f);
                     Tri6Regs L = load_tri6(S.lights + li);
                     float u = rng_u01(rng);
                     float v = rng_u01(rng);
@@ -330,8 +332,8 @@ RT_DEV bool machine6_step(const SceneView6 &S, int ray_depth, Rng &rng, Machine6
                 if (dot(nd, norma) < 0) { ret = emission; evaluating = false; continue; }       // scene.cpp:64-66
                 float pdf = 0.f;
                 pdf += smax(0.f, dot(nd, norma) / RT_PI_F);                                     // distributions.h:55-58
-                if (S.n_components == 2) { pdf += light_pdf_sum6_fast(S, xo, nd, stack, deep_stack) / (float)S.n_lights; M.n_light++; }
-                pdf = pdf / (float)S.n_components;
+                if (S.n_components == 2) { pdf += light_pdf_sum6_fast(S, xo, nd, stack, deep_stack) / S.n_lights_f; M.n_light++; }
+                pdf = pdf / S.n_components_f;
                 float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)dot(nd, norma));       // scene.cpp:69
                 f.kind = F6_MUL; f.emission = emission; f.mult = k * color;
                 fp++;

@@ -133,7 +133,7 @@ RT_DEV F3 trace_path(const SceneView &S, int ray_depth, Rng &rng, F3 o, F3 d, ui
         F3 x = o + h.t * d;                                                    // scene.cpp:104
         F3 xo = x + 9.99999974737875163555e-05f * ng;                          // x + eps * geomNorma, eps = (float)1e-4L
         // Mix::sample (distributions.h:256-265)
-        int comp = (int)(rng_u01(rng) * (float)S.n_components);
+        int comp = (int)(rng_u01(rng) * S.n_components_f);
         F3 nd;
         if (comp == 0) nd = cosine_sample(rng, sh.sn);
         else if (comp == 2) nd = light_sample(S, rng, xo);
@@ -147,8 +147,8 @@ RT_DEV F3 trace_path(const SceneView &S, int ray_depth, Rng &rng, F3 o, F3 d, ui
         float pdf = 0.f;
         pdf += cosine_pdf(sh.sn, nd);
         pdf += vndf_pdf(sh.sn, nd, d, sh.alpha);
-        if (S.n_components == 3) pdf += light_pdf_sum<COUNT>(S, xo, nd, stack, cnt) / (float)S.n_lights;
-        pdf = pdf / (float)S.n_components;
+        if (S.n_components == 3) pdf += light_pdf_sum<COUNT>(S, xo, nd, stack, cnt) / S.n_lights_f;
+        pdf = pdf / S.n_components_f;
         float k = (float)(1. / (double)pdf * fabs((double)dot(nd, sh.sn)));                                   // :159
         F3 mult = k * brdf;
         if (mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z) {

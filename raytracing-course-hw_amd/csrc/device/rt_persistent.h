@@ -40,13 +40,14 @@ namespace dev {
 #define PT_THREADS 1024               // hw6 (rt_persistent_hw6.h): one 16-wave workgroup per CU
 #define PT_WAVES 16
 // hw8 / hw7: workgroups of FOUR waves (one per SIMD), FIVE resident per CU = five waves per SIMD.  That takes <= 96 VGPRs per wave (no
-// scratch), 24-entry stack columns (4 x 24 x 256 B = 24 KB per workgroup) and 1 byte of LDS per path for the bitmaps: 31.8 KB per
+// scratch), 24-entry stack columns (4 x 24 x 256 B = 24 KB per workgroup) and 1.4 bytes of LDS per path for bitmaps and group tables: 31.7 KB per
 // workgroup, five of which fill the CU's 160 KB (handed out in 1,280-byte granules: 25 granules each).
 #define P8_WAVES 4
 #define P8_THREADS (64 * P8_WAVES)
 #define P8_PER_CU 5
 #define P8_STACK 24                   // LDS traversal stack entries per lane; the walkers' tree is built at most this deep (rt_bvh_build.h)
-#define PT_MAX_PATHS 7168             // paths per workgroup (bitmap capacity in LDS): x 1,280 workgroups = 9.2 M, a 3840x2160 frame in one pass
+#define PT_MAX_PATHS 5120             // paths per workgroup (bitmap capacity in LDS): x 1,280 workgroups = 6.5 M (a 3840x2160 frame on one GPU: two passes)
+#define PT_MIN_GROUP 16               // smallest group of the deal (group_shift 4): the LDS tables are sized for it
 #define PT_NW (PT_MAX_PATHS / 32)
 #define PT_BIT_T 1u                   // pending: closest-hit walk outstanding
 #define PT_BIT_L 2u                   // pending: light-pdf sum outstanding
@@ -60,6 +61,7 @@ namespace dev {
 #define PT_N_LIVE 5                   // cnt only: pixels of this workgroup not finished yet
 #define PT_W_TRACE 6                  // cnt only: waves currently walking closest hits / light sums
 #define PT_W_LIGHT 7
+#define PT_GSHIFT 15                  // cnt only: PtParams::group_shift (constant during the launch)
 // What a sub-tile costs its workgroup, in units of one closest-hit node step (wave time by role over steps by role on the benchmark
 // scene): the measure the frame is re-dealt by after its first phase.  Counting shaded hits alone misses the rays that hit nothing.
 #define PT_COST_TRACE_STEP 1u
@@ -72,15 +74,17 @@ struct PtShared {
     uint32_t stack[P8_WAVES][P8_STACK][64];   // per-lane traversal stack columns, one area per wave
     uint32_t need[5][PT_NW];
     uint32_t pending[PT_NW * 2];              // 2 bits per path
-    uint32_t groups[PT_MAX_PATHS / 64];       // local 64-slot group -> group of the pass (8x8 sub-tile)
-    uint32_t cost[PT_MAX_PATHS / 64];         // work done for each local group in this launch (PT_COST_*): the load measure the frame is re-dealt by
+    uint32_t groups[PT_MAX_PATHS / PT_MIN_GROUP]; // local group -> group of the pass
+    uint32_t cost[PT_MAX_PATHS / PT_MIN_GROUP];       // work done for each local group in this launch (PT_COST_*): the load measure the frame is re-dealt by
     int cnt[16];
 };
 static_assert(PT_EXACT_BATCH * RT_STACK_SIZE <= P8_STACK * 64, "the exact role's stacks must fit the wave's LDS stack area");
 static_assert(sizeof(PtShared) <= 25 * 1280, "five workgroups per CU: 25 LDS granules of 1,280 bytes each");
 
 struct PtParams {
-    uint32_t n_groups;                // 64-slot groups (8x8 sub-tiles) of this pass
+    uint32_t n_groups;                // groups of this pass: 2^group_shift consecutive path slots each
+    uint32_t group_shift;             // 6: a group is an 8x8 sub-tile; 4: two rows of one (small frames: more, smaller units for the deal — a
+                                      // workgroup should hold well over a dozen, and a heavy 8x8 sub-tile alone can outweigh a workgroup's fair share)
     // Which groups a workgroup owns: group_ids[group_ofs[b] .. group_ofs[b + 1]) when group_ofs is set (the host's re-deal after
     // the first phase of a frame), else b, b + n_blocks, b + 2 n_blocks, ...; `resume` = the paths carry on from their records
     // (a later phase) instead of being seeded; group_cost[g] receives the number of hits shaded for group g in this launch.
@@ -88,8 +92,10 @@ struct PtParams {
     uint32_t *group_cost;
     uint32_t resume;
     int refill, leaf_batch;           // as in rt_wavefront.h (leaf_batch = batch | share << 16)
+    int shade_min;                    // a wave turns shader when this many paths wait for shading (64 = a full wave of them)
     int shade_thr0, shade_thr_step;   // wave w stops refilling its walkers when need_shade holds >= thr0 + w * step paths
     int cost_t, cost_l;               // relative cost of a closest-hit / light query (walker split)
+    uint32_t front_first;             // 1: the queues serve the front of the workgroup's group list first (the host sorted it by cost, most expensive first)
     int prio;                         // experiment: 1 = walker stints run at raised wave priority (s_setprio 2), 2 = shader batches do
     unsigned long long deadline_ticks; // 100 MHz ticks a wave may spend in this launch before it gives up (error)
     unsigned long long *counters;     // [0] closest-hit queries, [1] light queries, [2] node visits, [3] triangle tests, [10] discarded speculative hits, [12] exact closest hits, [13] exact light sums, [14] waves that gave up waiting (error)
@@ -108,10 +114,13 @@ struct PtProf {
 // wave-uniform state
 struct PtWave {
     uint32_t nw, n_local, n_blocks, block;
+    bool front_first;                 // pt_pop's from_start for the trace / light / shade queues (PtParams::front_first)
     uint32_t cur[5];
 };
 
-template <class SH> RT_DEV uint32_t pt_slot(const SH &sh, uint32_t l) { return (sh.groups[l >> 6] << 6) | (l & 63u); }
+// A workgroup's paths come in groups of 2^shift consecutive slots (PtParams::group_shift: 6 = an 8x8 sub-tile, 4 = two rows of one): the unit of the deal.
+template <class SH> RT_DEV uint32_t pt_gshift(const SH &sh) { return (uint32_t)__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh.cnt[PT_GSHIFT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+template <class SH> RT_DEV uint32_t pt_slot(const SH &sh, uint32_t l) { const uint32_t g = pt_gshift(sh); return (sh.groups[l >> g] << g) | (l & ((1u << g) - 1u)); }
 // A fresh LDS read each time; every lane reads the same word, and readfirstlane makes that explicit: the scheduler's decisions are
 // taken on SGPRs (scalar branches, wave-uniform by construction — the code under them uses __ballot / __shfl / lane-0 atomics).
 RT_DEV int pt_count(const int *p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
@@ -126,8 +135,11 @@ RT_DEV uint32_t pt_rank_below(unsigned long long m) {
 // wants 64 paths from a dense queue gets the two words of one 8x8 sub-tile (coherent rays) for two LDS atomics.  A word that
 // holds more paths than are wanted keeps its upper bits and the cursor stays on it, so the next request starts there (no
 // path is passed over).  Returns the local path index or PT_NONE.
-RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &cursor, bool want) {
+// from_start: every request sweeps from word 0 — the paths at the front of the workgroup's list (its most expensive sub-tiles after a
+// re-deal) are always served first, so the longest serial chains (a pixel's samples are serial) never wait behind cheap work.
+RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &cursor, bool want, bool from_start = false) {
     const uint32_t lane = threadIdx.x & 63u;
+    if (from_start) cursor = 0u;
     const unsigned long long wantmask = __ballot(want);
     const int need = __popcll(wantmask);
     const int my_rank = (int)pt_rank_below(wantmask);
@@ -207,7 +219,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     float cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // h_ray: absolute part of the look-behind (pt_look_behind)
     auto store_hit = [&]() { // the gate (pt_shade_item) decides with the runner-up's t whether this hit needs the exact walk
         wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(S.exact_boxes && hit != WF_MISS ? hit | pt_gap_code(best_t, t2) : hit));
-        if (P.group_cost) atomicAdd(&sh.cost[l >> 6], steps * PT_COST_TRACE_STEP);
+        if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * PT_COST_TRACE_STEP);
     };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -222,7 +234,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (!refill_ok) {}
             else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;      // shaders are behind: drain, then help them
             else if (pt_count(&sh.cnt[PT_Q_TRACE]) > 0) {
-                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active);
+                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 n_queries += __popcll(__ballot(got != PT_NONE));
                 if (got != PT_NONE) {
@@ -308,7 +320,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
-        if (P.group_cost) atomicAdd(&sh.cost[l >> 6], steps * PT_COST_LIGHT_STEP);
+        if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * PT_COST_LIGHT_STEP);
         if (overflow) { fin = l | 0x80000000u; return; }
         float v = 0.f;
         if (k == 1) v = __uint_as_float(stack[P8_STACK - 2][lane]);
@@ -337,7 +349,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         }
         int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
-        *pdf = *pdf + v / (float)S.n_lights;                                  // distributions.h:123,273
+        *pdf = *pdf + v / S.n_lights_f;                                  // distributions.h:123,273
         fin = l;
     };
     for (;;) {
@@ -353,7 +365,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (!refill_ok) {}
             else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
             else if (pt_count(&sh.cnt[PT_Q_LIGHT]) > 0) {
-                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active);
+                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 n_queries += __popcll(__ballot(got != PT_NONE));
                 if (got != PT_NONE) {
@@ -465,7 +477,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
         // The bounce at `depth` sampled the ray that was just traced; its pdf is complete now (Mix::pdf, distributions.h:268-278).
         float4 *e = wf_entry(W, slot, depth);
         const float4 e0 = e[0], e1 = e[1];
-        const float pdf = e0.w / (float)S.n_components;                             // :278
+        const float pdf = e0.w / S.n_components_f;                             // :278
         const float k = (float)(1. / (double)pdf * fabs((double)e1.w));             // scene.cpp:159
         F3 mult = k * f3(e1.x, e1.y, e1.z);
         const bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
@@ -500,7 +512,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
             // only the random draws must still happen, in order (distributions.h:257, then 3 normals | u1,u2 | index,u,v).
             pk.end(emission_fetch(S, h), depth);
             Rng rng = pk.rng(packed);
-            const int comp = (int)(rng_u01(rng) * (float)S.n_components);
+            const int comp = (int)(rng_u01(rng) * S.n_components_f);
             if (comp == 0) { rng_n01(rng); rng_n01(rng); rng_n01(rng); }
             else if (comp == 2) { rng_u01(rng); rng_u01(rng); rng_u01(rng); }
             else { rng_u01(rng); rng_u01(rng); }
@@ -530,7 +542,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
             F3 nd;
             {   // Mix::sample (distributions.h:256-265)
                 Rng rng = pk.rng(packed);
-                const int comp = (int)(rng_u01(rng) * (float)S.n_components);         // :257
+                const int comp = (int)(rng_u01(rng) * S.n_components_f);         // :257
                 if (comp == 0) nd = cosine_sample(rng, sn);
                 else if (comp == 2) { const float4 xq = r[0]; nd = light_sample(S, rng, f3(xq.x, xq.y, xq.z)); }
                 else nd = vndf_sample(rng, sn, pk.get3(PK_D), alpha);
@@ -592,7 +604,7 @@ RT_DEV void pt_exact_batch(const SceneView &S, const WfView &W, SH &sh, PtWave &
         else { Counters c; c.closest = c.lightq = c.nodes = c.tris = 0; v = light_pdf_sum<false, PT_EXACT_BATCH>(S, x, d, xstack, c); }
         int depth = (int)(__float_as_uint(r[3].w) & 15u);
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
-        *pdf = *pdf + v / (float)S.n_lights;
+        *pdf = *pdf + v / S.n_lights_f;
     }
     n_xlight += __popcll(__ballot(got != PT_NONE));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -624,11 +636,12 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     PtWave wv;
     wv.n_blocks = gridDim.x; wv.block = blockIdx.x;
+    wv.front_first = P.front_first != 0u;
     const uint32_t first_group = P.group_ofs ? P.group_ofs[wv.block] : 0u;
     const uint32_t n_local_groups = P.group_ofs ? P.group_ofs[wv.block + 1u] - first_group
                                                 : (P.n_groups > wv.block ? (P.n_groups - wv.block + wv.n_blocks - 1u) / wv.n_blocks : 0u);
-    wv.n_local = n_local_groups * 64u;
-    wv.nw = n_local_groups * 2u;
+    wv.n_local = n_local_groups << P.group_shift;
+    wv.nw = (wv.n_local + 31u) >> 5;
     if (wv.n_local == 0u) return;
     if (P.debug && tid == 0) { P.debug[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); P.debug[3 * blockIdx.x + 2] = wv.n_local; }
     for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
@@ -637,7 +650,7 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
     for (uint32_t i = tid; i < wv.nw; i += P8_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
     for (uint32_t i = tid; i < 2u * wv.nw; i += P8_THREADS) sh.pending[i] = 0;
     for (uint32_t i = tid; i < n_local_groups; i += P8_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
-    if (tid < 16u) sh.cnt[tid] = 0;
+    if (tid < 16u) sh.cnt[tid] = tid == PT_GSHIFT ? (int)P.group_shift : 0;
     __syncthreads();
     for (uint32_t base = 0; base < wv.n_local; base += P8_THREADS) {
         const uint32_t l = base + tid;
@@ -703,8 +716,8 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
             continue;
         }
         // shaders first when a full wave of paths waits (or when it is all there is to do)
-        if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
-            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true);
+        if (ns >= P.shade_min || (ns > 0 && nt + nl == 0)) {
+            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true, wv.front_first);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (P.prio == 2) __builtin_amdgcn_s_setprio(2);
             int todo = 0;
@@ -729,7 +742,7 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
             pt_push(sh, PT_Q_TRACE, got, next);
             pt_push(sh, PT_Q_LIGHT, got, with_light);
             pt_push(sh, PT_Q_XTRACE, got, got != PT_NONE && todo == PT_SHADE_EXACT);
-            if (got != PT_NONE && todo != PT_SHADE_EXACT) atomicAdd(&sh.cost[got >> 6], (uint32_t)PT_COST_SHADE);
+            if (got != PT_NONE && todo != PT_SHADE_EXACT) atomicAdd(&sh.cost[got >> pt_gshift(sh)], (uint32_t)PT_COST_SHADE);
             const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == WF_PARKED)); // finished, or parked for the next phase
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;

@@ -23,9 +23,22 @@
 namespace rtamd {
 namespace dev {
 
-#define P6_STACK 36                  // LDS stack entries per lane (RT6_LDS_STACK: practice6_2's own trees are up to 36 deep)
-#define P6_MAX_PATHS 8192            // paths per workgroup: with 36-entry stacks the bitmaps get 8 KB
+// As rt_persistent.h: workgroups of four waves (one per SIMD), five per CU = five waves per SIMD (<= 96 VGPRs, no scratch).
+#define P6_WAVES 4
+#define P6_THREADS (64 * P6_WAVES)
+#define P6_PER_CU 5
+#define P6_STACK 28                  // LDS stack entries per lane: the scene tree (GPU-built, depth <= 28) and the own tree over the lights must fit
+#define P6_MAX_PATHS 2304            // paths per workgroup: 4 x 28 x 256 B of stacks + 1.4 B per path = 31.9 KB, five workgroups per CU
 #define P6_NW (P6_MAX_PATHS / 32)
+// The rare roles that need work arrays per query (exact walks, light sums at a box boundary or with many hits) run P6_XBATCH queries at
+// a time and keep those arrays in the wave's LDS stack area, idle meanwhile: word i of lane j's slice at area[P6_XBATCH * i + j],
+// 224 words per slice.  No scratch.
+#define P6_XBATCH 8
+#define P6_SLICE_WORDS (P6_STACK * 64 / P6_XBATCH)
+#define P6_COST_TRACE_STEP 1u        // what a sub-tile costs its workgroup, in closest-hit node steps (the measure of the re-deal, as PT_COST_*)
+#define P6_COST_LIGHT_STEP 2u
+#define P6_COST_SHADE 10u
+#define P6_MERGE_HITS 13             // p6_merge_hits works in the lane's own 28-word column: 13 terms + 14 index / depth words
 #define P6_Q_SLOW 3                  // light sums with more than two hits: the complete per-lane light_pdf_sum6_fast
 #define P6_REC 56u                   // float4 per path record: 8 + 5 per frame x RT6_MAX_DEPTH + 8 for the hits of a light sum
 // record: r0 = o.xyz d.x | r1 = d.yz rng.x rng.saved | r2 = hit t, figure slot, inside, t of the runner-up | r3 = accum.xyz packed
@@ -44,12 +57,22 @@ namespace dev {
 #define P6_PARKED 8
 #define P6_EXACT 16                  // the hit does not stand as the reference's answer: exact walk first, nothing of the path was touched
 
+struct P6Slice { // a strided view of the wave's LDS stack area: indexable like an array
+    uint32_t *p;
+    RT_DEV uint32_t &operator[](int i) const { return p[P6_XBATCH * i]; }
+    RT_DEV P6Slice at(int first_word) const { P6Slice s; s.p = p + P6_XBATCH * first_word; return s; }
+};
+struct P6SliceF { // the same words read as floats
+    uint32_t *p;
+    RT_DEV float &operator[](int i) const { return reinterpret_cast<float *>(p)[P6_XBATCH * i]; }
+};
+
 struct P6Shared {
-    uint32_t stack[PT_WAVES][P6_STACK][64];
+    uint32_t stack[P6_WAVES][P6_STACK][64];
     uint32_t need[5][P6_NW];
     uint32_t pending[P6_NW * 2];
-    uint32_t groups[P6_MAX_PATHS / 64];
-    uint32_t cost[P6_MAX_PATHS / 64];     // shader steps per local sub-tile in this launch: the load measure of the re-deal
+    uint32_t groups[P6_MAX_PATHS / PT_MIN_GROUP];
+    uint32_t cost[P6_MAX_PATHS / PT_MIN_GROUP];   // shader steps per local sub-tile in this launch: the load measure of the re-deal
     int cnt[16];
 };
 
@@ -94,8 +117,8 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
         const float4 q4 = r[4], q5 = r[5], q6 = r[6];
         float pdf = 0.f;
         pdf += q5.w;
-        if (S.n_components == 2) pdf += q4.w / (float)S.n_lights;
-        pdf = pdf / (float)S.n_components;
+        if (S.n_components == 2) pdf += q4.w / S.n_lights_f;
+        pdf = pdf / S.n_components_f;
         const float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)q6.w);                   // scene.cpp:69
         float4 *f = r + 8 + 5 * fp;
         f[0] = make_float4(q5.x, q5.y, q5.z, __uint_as_float((uint32_t)F6_MUL));
@@ -121,11 +144,11 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
             const F3 x = o + q2.x * d;                                                          // scene.cpp:60
             if (kind == RT_MAT_DIFFUSE) {
                 const F3 xo = x + epsf * norma;
-                int comp = (int)(rng_u01(rng) * (float)S.n_components);                         // distributions.h:284
+                int comp = (int)(rng_u01(rng) * S.n_components_f);                         // distributions.h:284
                 F3 nd;
                 if (comp == 0) nd = cosine_sample(rng, norma);
                 else {                                                                          // :199-208, :129-141
-                    int li = (int)(rng_u01(rng) * (float)S.n_lights);
+                    int li = (int)(rng_u01(rng) * S.n_lights_f);
                     Tri6Regs L = load_tri6(S.lights + li);
                     float u = rng_u01(rng);
                     float v = rng_u01(rng);
@@ -156,7 +179,7 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
                     // no lights in the scene: the pdf is complete (Mix = {Cosine})
                     float pdf = 0.f;
                     pdf += pdf_cos;
-                    pdf = pdf / (float)S.n_components;
+                    pdf = pdf / S.n_components_f;
                     const float k = (float)(1. / (double)(RT_PI_F * pdf) * (double)dnn);
                     float4 *f = r + 8 + 5 * fp;
                     f[0] = make_float4(emission.x, emission.y, emission.z, __uint_as_float((uint32_t)F6_MUL));
@@ -261,6 +284,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     uint32_t l = 0, slot = 0, cur = 0, hit = 0xFFFFFFFFu, best_ref = 0xFFFFFFFFu, fin = PT_NONE;
     bool best_inside = false;
     int sp = 0;
+    uint32_t steps = 0; // node steps + triangle tests of the lane's walk: the cost measure of the re-deal
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     float best_t = RT_T_MAX, cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // look-behind and runner-up: rt_exact.h
@@ -275,7 +299,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
             if (!refill_ok) {}
             else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
             else if (pt_count(&sh.cnt[PT_Q_TRACE]) > 0) {
-                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active);
+                const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 n_queries += __popcll(__ballot(got != PT_NONE));
                 if (got != PT_NONE) {
@@ -285,6 +309,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = make_ray_inv(o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
+                    steps = 0;
                     cur = 0; sp = 0; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
                     active = true;
                 }
@@ -300,6 +325,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
+                steps++;
                 float n0, n1;
                 bool h0 = slab_test(lo0, hi0, ray, cull_t, n0);
                 bool h1 = slab_test(lo1, hi1, ray, cull_t, n1);
@@ -309,6 +335,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                 else if (h1) cur = c1;
                 else if (sp == 0) {
                     p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
+                    if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_TRACE_STEP);
                     active = false; fin = l;
                 } else cur = stack[--sp][lane];
             }
@@ -319,6 +346,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                 for (;;) {
                     Tri6Regs T = load_tri6(S.tris + i);
                     if (COUNT) n_tris++;
+                    steps++;
                     float t; bool inside;
                     // reference tie rule: smallest t, equal t -> lowest index in the reference's figure order
                     if (tri6_test_closer(T, o, d, cull_t, t, inside)) {
@@ -334,6 +362,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
             }
             if (sp == 0) {
                 p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
+                if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_TRACE_STEP);
                 active = false; fin = l;
             } else cur = stack[--sp][lane];
         }
@@ -347,20 +376,22 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
     const int lane = threadIdx.x & 63;
     bool active = false, refill_ok = true, many = false, fragile = false; // fragile: a hit at a box boundary, the sum goes to the exact walk
-    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, slow = PT_NONE, idx0 = 0, idx1 = 0;
+    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, idx0 = 0, idx1 = 0; // fin: the lane's finished, unpublished path; bit 31 = it goes to the slow role
     int sp = 0, k = 0;
+    uint32_t steps = 0;
     float term0 = 0.f, term1 = 0.f;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
     auto finish = [&]() {
         active = false;
+        if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_LIGHT_STEP);
         if (fragile) { // the hits go along (also when there are fewer than three), the slow role adds them with the reference's box tests
             float2 *h = reinterpret_cast<float2 *>(p6_rec(W, slot) + 48);
             if (k >= 1 && k <= 2) h[0] = make_float2(__uint_as_float(idx0), term0);
             if (k == 2) h[1] = make_float2(__uint_as_float(idx1), term1);
-            reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k | 0x80000000u; slow = l; return;
+            reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k | 0x80000000u; fin = l | 0x80000000u; return;
         }
-        if (many) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k; slow = l; return; }
+        if (many) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k; fin = l | 0x80000000u; return; }
         const float v = k == 0 ? 0.f : (k == 1 ? term0 : term0 + term1);
         reinterpret_cast<float *>(p6_rec(W, slot) + 4)[3] = v;
         fin = l;
@@ -368,16 +399,17 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
-            if (__ballot(fin != PT_NONE || slow != PT_NONE)) {
+            if (__ballot(fin != PT_NONE)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE);
-                pt_push(sh, P6_Q_SLOW, slow, slow != PT_NONE);
-                fin = PT_NONE; slow = PT_NONE;
+                const bool slow = fin != PT_NONE && (fin >> 31) != 0u;
+                pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE && !slow);
+                pt_push(sh, P6_Q_SLOW, fin & 0x7FFFFFFFu, slow);
+                fin = PT_NONE;
             }
             if (!refill_ok) {}
             else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;
             else if (pt_count(&sh.cnt[PT_Q_LIGHT]) > 0) {
-                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active);
+                const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 n_queries += __popcll(__ballot(got != PT_NONE));
                 if (got != PT_NONE) {
@@ -386,6 +418,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     float4 q0 = r[0], q1 = r[1], q4 = r[4];
                     o = f3(q4.x, q4.y, q4.z); d = f3(q0.w, q1.x, q1.y);                        // the pdf's ray: x + eps*n towards the sampled direction
                     ray = make_ray_inv(o, d);
+                    steps = 0;
                     cur = 0; sp = 0; k = 0; many = false; fragile = false; term0 = 0.f; term1 = 0.f;
                     active = true;
                 }
@@ -401,6 +434,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                 const float4 *q = reinterpret_cast<const float4 *>(S.fast_light_nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
+                steps++;
                 float n0, n1;
                 bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
                 bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
@@ -418,6 +452,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                 for (;;) {
                     Tri6Regs T = load_tri6(S.fast_lights + i);
                     if (COUNT) n_tris++;
+                    steps++;
                     float t; bool inside;
                     if (tri6_test(T, o, d, t, inside)) {
                         F3 yn = normalize(inside ? neg(T.n) : T.n);                          // primitives.cpp:31
@@ -454,30 +489,31 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
 // that separate deepest in the reference tree (SceneView6::light_sep; inside a leaf the pseudo depths give ((a + b) + c)).  That is
 // an operator-precedence evaluation with the separation depth as the precedence, done in place in the lane's LDS stack column:
 // words 0..15 hold the terms and then the value stack, words 16..31 the light indices and then the depth stack. ---------------------
-RT_DEV float p6_merge_hits(const SceneView6 &S, const float2 *h, int k, uint32_t (*col)[64]) {
+RT_DEV float p6_merge_hits(const SceneView6 &S, const float2 *h, int k, uint32_t (*col)[64]) { // k <= P6_MERGE_HITS
     const int lane = threadIdx.x & 63;
+    const int I = P6_MERGE_HITS;                              // words 0..I-1: terms / value stack; words I..: light indices / depth stack
     for (int i = 0; i < k; i++) { // insertion sort by the reference's light index
         const float2 e = h[i];
         const uint32_t id = __float_as_uint(e.x);
         int j = i - 1;
-        while (j >= 0 && col[16 + j][lane] > id) { col[17 + j][lane] = col[16 + j][lane]; col[j + 1][lane] = col[j][lane]; j--; }
-        col[17 + j][lane] = id; col[j + 1][lane] = __float_as_uint(e.y);
+        while (j >= 0 && col[I + j][lane] > id) { col[I + 1 + j][lane] = col[I + j][lane]; col[j + 1][lane] = col[j][lane]; j--; }
+        col[I + 1 + j][lane] = id; col[j + 1][lane] = __float_as_uint(e.y);
     }
     const uint32_t nl = S.n_lights;
-    int vs = 1, os = 0;                                   // value stack: words 0..vs-1; depth stack: words 16..16+os-1
-    uint32_t prev = col[16][lane];
+    int vs = 1, os = 0;                                   // value stack: words 0..vs-1; depth stack: words I..I+os-1
+    uint32_t prev = col[I][lane];
     for (int i = 1; i < k; i++) {
-        const uint32_t id = col[16 + i][lane];
+        const uint32_t id = col[I + i][lane];
         const float term = __uint_as_float(col[i][lane]);
         const uint32_t len = id - prev, lv = 31u - (uint32_t)__clz((int)len);
         const uint16_t m0 = S.light_sep[(size_t)lv * nl + prev], m1 = S.light_sep[(size_t)lv * nl + (id - (1u << lv))];
         const uint32_t depth = m0 < m1 ? m0 : m1;          // where the hits prev and id separate
-        while (os > 0 && col[15 + os][lane] > depth) {     // the groups on the stack that separate deeper are complete: fold them
+        while (os > 0 && col[I - 1 + os][lane] > depth) {  // the groups on the stack that separate deeper are complete: fold them
             const float b = __uint_as_float(col[vs - 1][lane]), a = __uint_as_float(col[vs - 2][lane]);
             col[vs - 2][lane] = __float_as_uint(a + b);
             vs--; os--;
         }
-        col[16 + os][lane] = depth; os++;
+        col[I + os][lane] = depth; os++;                   // os <= i - 1 < the index words already consumed: never overwrites an unread index
         col[vs][lane] = __float_as_uint(term); vs++;
         prev = id;
     }
@@ -491,7 +527,8 @@ RT_DEV float p6_merge_hits(const SceneView6 &S, const float2 *h, int k, uint32_t
 
 // ---- exact role: BVH::intersect_ of hw6 (bvh.h, identical to hw8's) over the reference's own tree with the reference's box test, as an
 // iterative depth-first walk, left child first, one running best with strict '<' (ref_closest_hit of rt_exact.h with hw6's figures) ----
-RT_DEV void ref_closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack, float &best_t, bool &best_inside, uint32_t &hit) {
+template <class A>
+RT_DEV void ref_closest_hit6(const SceneView6 &S, F3 o, F3 d, A stack, float &best_t, bool &best_inside, uint32_t &hit) {
     best_t = RT_T_MAX; best_inside = false; hit = 0xFFFFFFFFu;
     if (S.n_tris == 0) return;
     int sp = 0;
@@ -520,7 +557,8 @@ RT_DEV void ref_closest_hit6(const SceneView6 &S, F3 o, F3 d, uint32_t *stack, f
 // lead to them -- every node on such a path gets the reference's box test and pruning rule, every hit its triangle test again, in
 // the reference's order.  A few hundred box tests instead of tens of thousands; more hits than P6_XHITS fall back to the blind walk.
 #define P6_XHITS 48
-RT_DEV bool p6_all_hits(const SceneView6 &S, F3 o, F3 d, uint32_t *stack, uint32_t *hits, int &k) { // unsorted reference indices; false = too many
+template <class A, class B>
+RT_DEV bool p6_all_hits(const SceneView6 &S, F3 o, F3 d, A stack, B hits, int &k) { // unsorted reference indices; false = too many
     RayInv ray = make_ray_inv(o, d);
     int sp = 0; k = 0;
     uint32_t cur = 0;
@@ -551,11 +589,13 @@ RT_DEV bool p6_all_hits(const SceneView6 &S, F3 o, F3 d, uint32_t *stack, uint32
         else { if (sp == 0) return true; cur = stack[--sp]; }
     }
 }
-RT_DEV void p6_sort_hits(uint32_t *hits, int k) {
+template <class B>
+RT_DEV void p6_sort_hits(B hits, int k) {
     for (int i = 1; i < k; i++) { const uint32_t v = hits[i]; int j = i - 1; while (j >= 0 && hits[j] > v) { hits[j + 1] = hits[j]; j--; } hits[j + 1] = v; }
 }
 // BVH::intersect_ restricted to the paths towards hits[lo..hi): stack words = node | lo << 19 | hi << 25 (node < 2^19, k <= 63)
-RT_DEV void ref_closest_hit6_along(const SceneView6 &S, F3 o, F3 d, const uint32_t *hits, int k, uint32_t *stack, float &best_t, bool &best_inside, uint32_t &hit) {
+template <class A, class B>
+RT_DEV void ref_closest_hit6_along(const SceneView6 &S, F3 o, F3 d, B hits, int k, A stack, float &best_t, bool &best_inside, uint32_t &hit) {
     best_t = RT_T_MAX; best_inside = false; hit = 0xFFFFFFFFu;
     if (k == 0) return;
     int sp = 0;
@@ -589,7 +629,9 @@ RT_DEV void ref_closest_hit6_along(const SceneView6 &S, F3 o, F3 d, const uint32
 }
 // FiguresMix::getTotalPdf restricted to the paths towards the hit lights (sorted by index): the addition tree of light_sum6_associate
 // with the reference's box test at every node on the way (a failed box contributes 0 whatever lies below it).
-RT_DEV float ref_light_pdf_sum6_along(const SceneView6 &S, F3 x, F3 d, uint32_t *hit_idx, float *hit_term, int k) {
+// hit_idx / hit_term: RT6_MAX_LIGHT_HITS words each; `work`: 4 x RT6_MAX_LIGHT_HITS words for the frames of the recursion.
+template <class A, class AF>
+RT_DEV float ref_light_pdf_sum6_along(const SceneView6 &S, F3 x, F3 d, A hit_idx, AF hit_term, int k, A f_node, A f_lo, A f_hi, AF f_val) {
     if (k == 0) return 0.f;
     for (int i = 1; i < k; i++) {
         uint32_t id = hit_idx[i]; float tm = hit_term[i];
@@ -597,7 +639,7 @@ RT_DEV float ref_light_pdf_sum6_along(const SceneView6 &S, F3 x, F3 d, uint32_t 
         while (j >= 0 && hit_idx[j] > id) { hit_idx[j + 1] = hit_idx[j]; hit_term[j + 1] = hit_term[j]; j--; }
         hit_idx[j + 1] = id; hit_term[j + 1] = tm;
     }
-    uint32_t f_node[RT6_MAX_LIGHT_HITS]; int f_lo[RT6_MAX_LIGHT_HITS], f_hi[RT6_MAX_LIGHT_HITS]; float f_val[RT6_MAX_LIGHT_HITS]; uint32_t f_add = 0;
+    uint32_t f_add = 0;
     int fsp = 0;
     uint32_t node = 0; int lo = 0, hi = k;
     float v = 0.f;
@@ -612,14 +654,14 @@ RT_DEV float ref_light_pdf_sum6_along(const SceneView6 &S, F3 x, F3 d, uint32_t 
             while (m < hi && hit_idx[m] < right_first) m++;
             if (m == lo) { node = n.right; continue; }
             if (m == hi) { node = n.left; continue; }
-            f_node[fsp] = n.right; f_lo[fsp] = m; f_hi[fsp] = hi; f_add &= ~(1u << fsp); fsp++;
+            f_node[fsp] = n.right; f_lo[fsp] = (uint32_t)m; f_hi[fsp] = (uint32_t)hi; f_add &= ~(1u << fsp); fsp++;
             node = n.left; hi = m;
         }
         for (;;) {
             if (fsp == 0) return v;
             fsp--;
             if ((f_add >> fsp) & 1u) { v = f_val[fsp] + v; continue; }
-            node = f_node[fsp]; lo = f_lo[fsp]; hi = f_hi[fsp];
+            node = f_node[fsp]; lo = (int)f_lo[fsp]; hi = (int)f_hi[fsp];
             f_val[fsp] = v; f_add |= 1u << fsp; fsp++;
             break;
         }
@@ -629,7 +671,8 @@ RT_DEV float ref_light_pdf_sum6_along(const SceneView6 &S, F3 x, F3 d, uint32_t 
 // FiguresMix::getTotalPdf of hw6 (distributions.h:212-256) over the reference's own light tree with the reference's box test and its
 // association of the additions (ref_light_pdf_sum of rt_exact.h with hw6's term).  The tree is degenerate (85 levels on practice6_2):
 // thousands of box tests per query, which is why only light sums with a hit at a box boundary come here.
-RT_DEV float ref_light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack) {
+template <class A>
+RT_DEV float ref_light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, A stack) {
     int sp = 0;
     unsigned long long mask_lo = 0, mask_hi = 0;
     uint32_t cur = 0;
@@ -673,27 +716,89 @@ RT_DEV float ref_light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, uint32_t *stack
     return v;
 }
 
+// ---- the rare roles, P6_XBATCH queries at a time, work arrays in the wave's LDS stack area (P6Slice) ----------------------------------
+// Light sums the walker could not finish: a hit at a box boundary (the reference's own box tests decide, along the paths to the hits),
+// or more hits than p6_merge_hits takes (the plain reference-order walk).
+template <class SH>
+RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &wv, uint32_t *area, uint32_t got, bool mine, uint32_t &n_xlight) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = 0; base < 64u; base += P6_XBATCH) { // the wave's lanes take turns at the slices, eight at a time
+        if (!__ballot(mine && lane >= base && lane < base + P6_XBATCH)) continue;
+        if (mine && lane >= base && lane < base + P6_XBATCH) {
+            P6Slice sl; sl.p = area + (lane - base);
+            float4 *r = p6_rec(W, pt_slot(sh, got));
+            const uint32_t kw = reinterpret_cast<const uint32_t *>(r + 7)[0];
+            const int k = (int)(kw & 0x7FFFFFFFu);
+            const float4 q0 = r[0], q1 = r[1], q4 = r[4];
+            const F3 lx = f3(q4.x, q4.y, q4.z), ld = f3(q0.w, q1.x, q1.y);
+            float v;
+            if (kw >> 31) { // a hit at a box boundary
+                if (k > RT6_MAX_LIGHT_HITS) v = ref_light_pdf_sum6(S, lx, ld, sl);
+                else {
+                    P6Slice hit_idx = sl.at(0), f_node = sl.at(32), f_lo = sl.at(48), f_hi = sl.at(64);
+                    P6SliceF hit_term; hit_term.p = sl.at(16).p;
+                    P6SliceF f_val; f_val.p = sl.at(80).p;
+                    const float2 *h = reinterpret_cast<const float2 *>(r + 48);
+                    for (int i = 0; i < k; i++) { const float2 e = h[i]; hit_idx[i] = __float_as_uint(e.x); hit_term[i] = e.y; }
+                    v = ref_light_pdf_sum6_along(S, lx, ld, hit_idx, hit_term, k, f_node, f_lo, f_hi, f_val);
+                }
+                n_xlight++;
+            } else v = light_pdf_sum6(S, lx, ld, sl); // more than P6_MERGE_HITS hits
+            reinterpret_cast<float *>(r + 4)[3] = v;
+        }
+    }
+}
+
+// Closest hits that do not stand as the reference's answer (~1e-4 of them): the reference's own walk.
+template <class SH>
+RT_DEV void p6_exact_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &wv, uint32_t *area, uint32_t &n_exact) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t got = pt_pop(sh.need[P6_Q_XTRACE], &sh.cnt[P6_Q_XTRACE], wv.nw, wv.cur[P6_Q_XTRACE], lane < P6_XBATCH);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (got != PT_NONE) {
+        P6Slice xstack; xstack.p = area + lane;             // words 0..127: node stack; words 128..175: the ray's hits
+        P6Slice xhits = xstack.at(RT6_STACK_SIZE);
+        float4 *r = p6_rec(W, pt_slot(sh, got));
+        const float4 q0 = r[0], q1 = r[1];
+        float bt; bool bin; uint32_t bhit;
+        int xk;
+        const F3 xo = f3(q0.x, q0.y, q0.z), xd = f3(q0.w, q1.x, q1.y);
+        if (S.n_tris < (1u << 18) /* the path stack packs node numbers into 19 bits */ && p6_all_hits(S, xo, xd, xstack, xhits, xk)) { p6_sort_hits(xhits, xk); ref_closest_hit6_along(S, xo, xd, xhits, xk, xstack, bt, bin, bhit); }
+        else ref_closest_hit6(S, xo, xd, xstack, bt, bin, bhit);
+        r[2] = make_float4(bt, __uint_as_float(bhit), __uint_as_float(bin ? 1u : 0u), 0.f);
+        float *pk = reinterpret_cast<float *>(r + 3) + 3;
+        *pk = __uint_as_float(__float_as_uint(*pk) | P6_VERIFIED);
+    }
+    n_exact += __popcll(__ballot(got != PT_NONE));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
+}
+static_assert(sizeof(P6Shared) <= 25 * 1280, "five workgroups per CU: 25 LDS granules of 1,280 bytes each");
+static_assert(RT6_STACK_SIZE + P6_XHITS <= P6_SLICE_WORDS && 6 * RT6_MAX_LIGHT_HITS <= P6_SLICE_WORDS, "the rare roles' work arrays must fit a slice of the wave's stack area");
+
 // ---- the kernel (scheduler of rt_persistent.h) ------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S, RenderView R, W6View W, PtParams P) {
+__global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(SceneView6 S, RenderView R, W6View W, PtParams P) {
     __shared__ P6Shared sh;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     PtWave wv;
     wv.n_blocks = gridDim.x; wv.block = blockIdx.x;
+    wv.front_first = P.front_first != 0u;
     const uint32_t first_group = P.group_ofs ? P.group_ofs[wv.block] : 0u;
     const uint32_t n_local_groups = P.group_ofs ? P.group_ofs[wv.block + 1u] - first_group
                                                 : (P.n_groups > wv.block ? (P.n_groups - wv.block + wv.n_blocks - 1u) / wv.n_blocks : 0u);
-    wv.n_local = n_local_groups * 64u;
-    wv.nw = n_local_groups * 2u;
+    wv.n_local = n_local_groups << P.group_shift;
+    wv.nw = (wv.n_local + 31u) >> 5;
     if (wv.n_local == 0u) return;
     for (int q = 0; q < 5; q++) wv.cur[q] = (wave * 64u) % wv.nw;
-    for (uint32_t i = tid; i < wv.nw; i += PT_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
-    for (uint32_t i = tid; i < 2u * wv.nw; i += PT_THREADS) sh.pending[i] = 0;
-    for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
-    if (tid < 16u) sh.cnt[tid] = 0;
+    for (uint32_t i = tid; i < wv.nw; i += P6_THREADS) { sh.need[0][i] = 0; sh.need[1][i] = 0; sh.need[2][i] = 0; sh.need[3][i] = 0; sh.need[4][i] = 0; }
+    for (uint32_t i = tid; i < 2u * wv.nw; i += P6_THREADS) sh.pending[i] = 0;
+    for (uint32_t i = tid; i < n_local_groups; i += P6_THREADS) { sh.groups[i] = P.group_ofs ? P.group_ids[first_group + i] : i * wv.n_blocks + wv.block; sh.cost[i] = 0; }
+    if (tid < 16u) sh.cnt[tid] = tid == PT_GSHIFT ? (int)P.group_shift : 0;
     if (P.debug && tid == 0) { P.debug[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); P.debug[3 * blockIdx.x + 2] = wv.n_local; }
     __syncthreads();
-    for (uint32_t base = 0; base < wv.n_local; base += PT_THREADS) { // seed every pixel, first camera ray (hw6/src/sceneio.cpp:281-284)
+    for (uint32_t base = 0; base < wv.n_local; base += P6_THREADS) { // seed every pixel, first camera ray (hw6/src/sceneio.cpp:281-284)
         const uint32_t l = base + tid;
         bool started = false;
         if (l < wv.n_local) {
@@ -737,45 +842,26 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
     uint32_t n_closest = 0, n_light = 0, n_slow = 0, n_exact = 0, n_xlight = 0;
     unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t idle_spins = 0;
+    bool gave_up = false;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_role[5] = {0, 0, 0, 0, 0}, t_mark = t_start; // COUNT: wave time as closest-hit walker, light walker, shader, slow light sums, idle
     auto clock_role = [&](int role) { if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_role[role] += now - t_mark; t_mark = now; } };
     for (;;) {
-        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { // safety net: never hang the GPU; the host reports the error
-            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
-            break;
-        }
+        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { gave_up = true; break; } // safety net: never hang the GPU; the host reports the error
         const int ns = pt_count(&sh.cnt[PT_Q_SHADE]), nt = pt_count(&sh.cnt[PT_Q_TRACE]), nl = pt_count(&sh.cnt[PT_Q_LIGHT]);
         if (pt_count(&sh.cnt[P6_Q_SLOW]) > 0) {
-            // light sums with more than two hits: the reference's association over the hits the walker left in the record, one lane
-            // per query (more than 16 hits: the plain reference-order walk)
-            uint32_t deep_stack[RT6_STACK_SIZE];
+            // light sums with more than two hits: the reference's association over the hits the walker left in the record, one lane per
+            // query in its own stack column (up to P6_MERGE_HITS hits, not at a box boundary); the others in batches (p6_slow_batch)
             const uint32_t got = pt_pop(sh.need[P6_Q_SLOW], &sh.cnt[P6_Q_SLOW], wv.nw, wv.cur[P6_Q_SLOW], true);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            bool batch = false;
             if (got != PT_NONE) {
                 float4 *r = p6_rec(W, pt_slot(sh, got));
                 const uint32_t kw = reinterpret_cast<const uint32_t *>(r + 7)[0];
-                const int k = (int)(kw & 0x7FFFFFFFu);
-                float v;
-                if (kw >> 31) { // a hit at a box boundary: the reference's own box tests decide
-                    const float4 q0 = r[0], q1 = r[1], q4 = r[4];
-                    const F3 lx = f3(q4.x, q4.y, q4.z), ld = f3(q0.w, q1.x, q1.y);
-                    if (k > RT6_MAX_LIGHT_HITS) v = ref_light_pdf_sum6(S, lx, ld, deep_stack);
-                    else {
-                        uint32_t hit_idx[RT6_MAX_LIGHT_HITS]; float hit_term[RT6_MAX_LIGHT_HITS];
-                        const float2 *h = reinterpret_cast<const float2 *>(r + 48);
-                        for (int i = 0; i < k; i++) { const float2 e = h[i]; hit_idx[i] = __float_as_uint(e.x); hit_term[i] = e.y; }
-                        v = ref_light_pdf_sum6_along(S, lx, ld, hit_idx, hit_term, k);
-                    }
-                    n_xlight++;
-                } else if (k > RT6_MAX_LIGHT_HITS) {
-                    const float4 q0 = r[0], q1 = r[1], q4 = r[4];
-                    v = light_pdf_sum6(S, f3(q4.x, q4.y, q4.z), f3(q0.w, q1.x, q1.y), deep_stack);
-                } else {
-                    v = p6_merge_hits(S, reinterpret_cast<const float2 *>(r + 48), k, stack);
-                }
-                reinterpret_cast<float *>(r + 4)[3] = v;
+                if ((kw >> 31) || kw > (uint32_t)P6_MERGE_HITS) batch = true;
+                else reinterpret_cast<float *>(r + 4)[3] = p6_merge_hits(S, reinterpret_cast<const float2 *>(r + 48), (int)kw, stack);
             }
+            if (__ballot(batch)) p6_slow_batch(S, W, sh, wv, &stack[0][0], got, batch, n_xlight); // the merges are done: their columns are free
             n_slow += __popcll(__ballot(got != PT_NONE));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
@@ -784,31 +870,13 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
             continue;
         }
         if (pt_count(&sh.cnt[P6_Q_XTRACE]) > 0) {
-            // hits that do not stand as the reference's answer (~1e-5 of them): the reference's own walk, one lane per query
-            uint32_t xstack[RT6_STACK_SIZE];
-            const uint32_t got = pt_pop(sh.need[P6_Q_XTRACE], &sh.cnt[P6_Q_XTRACE], wv.nw, wv.cur[P6_Q_XTRACE], true);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (got != PT_NONE) {
-                float4 *r = p6_rec(W, pt_slot(sh, got));
-                const float4 q0 = r[0], q1 = r[1];
-                float bt; bool bin; uint32_t bhit;
-                uint32_t xhits[P6_XHITS]; int xk;
-                const F3 xo = f3(q0.x, q0.y, q0.z), xd = f3(q0.w, q1.x, q1.y);
-                if (S.n_tris < (1u << 18) /* the path stack packs node numbers into 19 bits */ && p6_all_hits(S, xo, xd, xstack, xhits, xk)) { p6_sort_hits(xhits, xk); ref_closest_hit6_along(S, xo, xd, xhits, xk, xstack, bt, bin, bhit); }
-                else ref_closest_hit6(S, xo, xd, xstack, bt, bin, bhit);
-                r[2] = make_float4(bt, __uint_as_float(bhit), __uint_as_float(bin ? 1u : 0u), 0.f);
-                float *pk = reinterpret_cast<float *>(r + 3) + 3;
-                *pk = __uint_as_float(__float_as_uint(*pk) | P6_VERIFIED);
-            }
-            n_exact += __popcll(__ballot(got != PT_NONE));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
+            p6_exact_batch(S, W, sh, wv, &stack[0][0], n_exact);
             idle_spins = 0;
             clock_role(3);
             continue;
         }
-        if (ns >= 64 || (ns > 0 && nt + nl == 0)) {
-            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true);
+        if (ns >= P.shade_min || (ns > 0 && nt + nl == 0)) {
+            const uint32_t got = pt_pop(sh.need[PT_Q_SHADE], &sh.cnt[PT_Q_SHADE], wv.nw, wv.cur[PT_Q_SHADE], true, wv.front_first);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             int todo = 0;
             if (got != PT_NONE) todo = p6_advance(S, R, W, pt_slot(sh, got));
@@ -818,7 +886,7 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
             if (tr || li) atomicOr(&sh.pending[got >> 4], ((tr ? PT_BIT_T : 0u) | (li ? PT_BIT_L : 0u)) << ((got & 15u) * 2u));
             pt_push(sh, PT_Q_TRACE, got, tr);
             pt_push(sh, PT_Q_LIGHT, got, li);
-            if (got != PT_NONE && todo != P6_EXACT) atomicAdd(&sh.cost[got >> 6], 1u);
+            if (got != PT_NONE && todo != P6_EXACT) atomicAdd(&sh.cost[got >> pt_gshift(sh)], (uint32_t)P6_COST_SHADE);
             const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == P6_PARKED));
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;
@@ -844,22 +912,20 @@ __global__ __launch_bounds__(PT_THREADS) void p6_persistent_kernel(SceneView6 S,
         if (pt_count(&sh.cnt[PT_N_LIVE]) <= 0) break;
         __builtin_amdgcn_s_sleep(8);
         clock_role(4);
-        if (++idle_spins > (1u << 24)) {
-            if (lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
-            break;
-        }
+        if (++idle_spins > (1u << 24)) { gave_up = true; break; }
     }
+    if (gave_up && lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
     if (P.group_cost) { // every wave leaves the loop once the workgroup's pixels are done (or at the deadline)
         __syncthreads();
-        for (uint32_t i = tid; i < n_local_groups; i += PT_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
+        for (uint32_t i = tid; i < n_local_groups; i += P6_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];
     }
     if (lane == 0 && P.counters) {
         if (n_closest) atomicAdd(&P.counters[0], (unsigned long long)n_closest);
         if (n_light) atomicAdd(&P.counters[1], (unsigned long long)n_light);
         if (n_slow) atomicAdd(&P.counters[13], (unsigned long long)n_slow);
         if (n_exact) atomicAdd(&P.counters[12], (unsigned long long)n_exact);
-        if (n_xlight) atomicAdd(&P.counters[11], (unsigned long long)n_xlight);
     }
+    if (n_xlight && P.counters) atomicAdd(&P.counters[11], (unsigned long long)n_xlight); // per lane: each counted its own queries
     if (COUNT && P.counters) {
         atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris);
         if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&P.counters[16 + i], t_role[i]);

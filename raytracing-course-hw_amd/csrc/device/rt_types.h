@@ -97,6 +97,7 @@ struct SceneView {
     float box_c2x;                 // 1.25f * box_c2 (the walkers' absolute look-behind, rt_exact.h)
     uint32_t exact_boxes;          // 0 = accept every hit of the conservative walk (the round pipeline's behaviour)
     uint32_t n_tris, n_lights, n_components;
+    float n_lights_f, n_components_f; // the same numbers as floats (exact): a conversion in the kernel would sit in a VGPR for the whole launch
     uint32_t n_nodes;              // inner nodes of the scene BVH (`nodes`)
     // 1 when every material has 0 <= metallicFactor <= 1 and a non-negative base colour: then the BRDF is >= 0,
     // the throughput of the deepest level is in [0, inf] or NaN, and that level returns exactly its emission

@@ -39,6 +39,7 @@ struct SceneView6 {
     uint32_t exact_boxes;
     const GpuMaterial6 *materials;
     uint32_t n_tris, n_lights, n_components;
+    float n_lights_f, n_components_f; // the same numbers as floats (exact)
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];
     float bg[3];
     float tan_fov_y;

@@ -432,7 +432,7 @@ RT_DEV void wf_light_loop(const SceneView &S, const WfView &W, uint32_t (*stack)
                 } else if (sp == 0) { // sum complete
                     int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
                     float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
-                    *pdf = *pdf + v / (float)S.n_lights;
+                    *pdf = *pdf + v / S.n_lights_f;
                     active = false;
                 } else {
                     uint32_t f = wf_spop<SPILL>(stack, ovf, lds_limit, lane, sp);
@@ -517,7 +517,7 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
         }
         int depth = (int)(__float_as_uint(reinterpret_cast<const float *>(wf_rec(W, slot) + 3)[3]) & 15u);
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
-        *pdf = *pdf + v / (float)S.n_lights;                                  // distributions.h:123,273
+        *pdf = *pdf + v / S.n_lights_f;                                  // distributions.h:123,273
     };
     for (;;) {
         unsigned long long idle = __ballot(!active);
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(64) void wf_light_exact_kernel(SceneView S, WfView 
         float v = S.exact_boxes ? ref_light_pdf_sum(S, x, dir, stack) : light_pdf_sum<false>(S, x, dir, stack, cnt);
         int depth = (int)(__float_as_uint(r[3].w) & 15u);
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
-        *pdf = *pdf + v / (float)S.n_lights;
+        *pdf = *pdf + v / S.n_lights_f;
     }
 }
 
@@ -656,7 +656,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
         float4 *e = wf_entry(W, slot, depth);
         float4 e0 = e[0], e1 = e[1];
         F3 brdf = f3(e1.x, e1.y, e1.z);
-        float pdf = e0.w / (float)S.n_components;                              // :278
+        float pdf = e0.w / S.n_components_f;                              // :278
         float k = (float)(1. / (double)pdf * fabs((double)e1.w));              // scene.cpp:159
         F3 mult = k * brdf;
         bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
@@ -699,7 +699,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
                 // SceneView::last_level_emission_only).  Only the random draws must still happen, in order
                 // (distributions.h:257, then 3 normals | u1,u2 | index,u,v).
                 tail = emission_fetch(S, h);
-                int comp = (int)(rng_u01(rng) * (float)S.n_components);
+                int comp = (int)(rng_u01(rng) * S.n_components_f);
                 if (comp == 0) { rng_n01(rng); rng_n01(rng); rng_n01(rng); }
                 else if (comp == 2) { rng_u01(rng); rng_u01(rng); rng_u01(rng); }
                 else { rng_u01(rng); rng_u01(rng); }
@@ -722,7 +722,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
                     metallic_eff = sh.metallic * base_metallic;
                     alpha = sh.alpha; sn = sh.sn;
                 }
-                int comp = (int)(rng_u01(rng) * (float)S.n_components);               // distributions.h:257
+                int comp = (int)(rng_u01(rng) * S.n_components_f);               // distributions.h:257
                 F3 nd;
                 if (comp == 0) nd = cosine_sample(rng, sn);
                 else if (comp == 2) { const float4 xq = r[0]; nd = light_sample(S, rng, f3(xq.x, xq.y, xq.z)); }

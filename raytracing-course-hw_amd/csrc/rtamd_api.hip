@@ -77,7 +77,7 @@ struct rt_scene {
     SceneView5 view5{};
     bool txt_has_triangles = false; // TRIANGLE figures exist only in the hw5 grammar: such a scene renders with RT_INTEGRATOR_HW5 only
     int flavor = RT_INTEGRATOR_HW8; // which integrator this scene was prepared for
-    bool hw6_lds_stack = false;
+    bool hw6_lds_stack = false, hw6_pt_stack = false;
     std::vector<void *> allocations;
     rt_scene_info info{};
     std::vector<uint32_t> light_order;
@@ -273,6 +273,7 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
                 return fail(RT_ERR_LIMIT, "scene BVH deeper than the kernel's traversal stack (" + std::to_string(P6.bvh_depth) + "/" +
                                               std::to_string(P6.light_bvh_depth) + ")");
             s->hw6_lds_stack = P6.bvh_depth <= RT6_LDS_STACK && P6.fast_light_bvh_depth <= RT6_LDS_STACK; // both own trees fit the LDS stack columns
+            s->hw6_pt_stack = P6.bvh_depth <= P6_STACK && P6.fast_light_bvh_depth <= P6_STACK;           // ... of the persistent pipeline
             V.light_nodes = keep(upload(P6.light_nodes, bytes));
             V.lights = keep(upload(P6.lights, bytes));
             V.fast_light_nodes = keep(upload(P6.fast_light_nodes, bytes));
@@ -290,6 +291,7 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
             V.n_tris = desc->n_triangles;
             V.n_lights = (uint32_t)P6.lights.size();
             V.n_components = P6.lights.empty() ? 1u : 2u; // hw6/src/scene.cpp:8-16
+            V.n_lights_f = (float)V.n_lights; V.n_components_f = (float)V.n_components;
             for (int k = 0; k < 3; k++) {
                 V.cam_pos[k] = desc->camera.position[k]; V.cam_right[k] = desc->camera.right[k];
                 V.cam_up[k] = desc->camera.up[k]; V.cam_fwd[k] = desc->camera.forward[k];
@@ -389,6 +391,7 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
         V.n_nodes = n_nodes;
         V.n_lights = (uint32_t)P.lights.size();
         V.n_components = P.lights.empty() ? 2u : 3u; // scene.cpp:65-74
+        V.n_lights_f = (float)V.n_lights; V.n_components_f = (float)V.n_components;
         V.last_level_emission_only = 1;
         for (uint32_t i = 0; i < desc->n_materials; i++) {
             const rt_material &m = desc->materials[i];
@@ -638,9 +641,23 @@ static void launch_wavefront(rt_scene *scene, const SceneView &V, const RenderVi
 // costs measured over the long middle phase — measured: no gain (hw6 practice6_2 191.7 vs 193.6 Msamples/s, headline 284.2 vs 284.6):
 // what remains of the spread of the workgroups' exit times after one re-deal is not the amount of work but the serial samples of the
 // slowest pixels.
-static std::vector<int> phase_stops(bool rebalance, int phase0, int samples, int default_phases) {
+static std::vector<int> phase_stops(bool rebalance, int phase0, int samples, int default_phases, bool small_population) {
     std::vector<int> stops;
+    if (rebalance && getenv("RTAMD_PT_STOPS")) { // experiment: explicit sample counts at which the frame is re-dealt, e.g. "2,16"
+        int last = 0;
+        for (const char *c = getenv("RTAMD_PT_STOPS"); *c;) {
+            const int v = atoi(c);
+            if (v > last && v < samples) { stops.push_back(v); last = v; }
+            while (*c && *c != ',') c++;
+            if (*c == ',') c++;
+        }
+        stops.push_back(samples);
+        return stops;
+    }
     if (rebalance) {
+        // small populations (the deal is in quarter sub-tiles): a first re-deal after two samples already — the round-robin deal of the
+        // first phase is the costly one there (slowest workgroup / mean 1.8 on hw6's 1024x1024 frame) — then the usual one
+        if (small_population && phase0 > 2 && !getenv("RTAMD_PT_PHASE0")) stops.push_back(2);
         stops.push_back(phase0);
         const int want = getenv("RTAMD_PT_PHASES") ? atoi(getenv("RTAMD_PT_PHASES")) : default_phases;
         const int mid = phase0 + (samples - phase0) * 3 / 4;
@@ -716,8 +733,10 @@ static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_o
     }
     ofs.assign(blocks + 1, 0);
     if (owner) owner->assign(groups, 0);
+    const bool by_cost = !getenv("RTAMD_PT_NO_FRONT_FIRST"); // most expensive group first: the kernel's queues serve the front of the list first (PtParams::front_first)
     for (uint32_t b = 0; b < blocks; b++) {
-        std::sort(mine[b].begin(), mine[b].end());
+        if (by_cost) std::sort(mine[b].begin(), mine[b].end(), [&](uint32_t x, uint32_t y) { return cost[x] != cost[y] ? cost[x] > cost[y] : x < y; });
+        else std::sort(mine[b].begin(), mine[b].end());
         ofs[b] = (uint32_t)ids.size();
         ids.insert(ids.end(), mine[b].begin(), mine[b].end());
         if (owner) for (uint32_t g : mine[b]) (*owner)[g] = b;
@@ -753,10 +772,15 @@ static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_o
 static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
     uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus * P8_PER_CU); // five 4-wave workgroups per CU (their LDS fills the CU)
-    const uint32_t groups_per_block = PT_MAX_PATHS / 64;
-    const uint64_t pass_cap = (uint64_t)n_blocks_max * groups_per_block;
+    const uint64_t pass_cap = (uint64_t)n_blocks_max * (PT_MAX_PATHS / 64);
     const uint32_t passes = (uint32_t)((n_work + pass_cap - 1) / pass_cap);
-    const uint32_t pass_groups = (n_work + passes - 1) / passes;
+    const uint32_t pass_groups = (n_work + passes - 1) / passes;         // 8x8 sub-tiles (64 path slots) per pass
+    // The unit of the deal: an 8x8 sub-tile, or — when a workgroup would hold fewer than sixteen of those (small frames, shards) — a
+    // quarter of one (two pixel rows): a single heavy sub-tile must not outweigh a workgroup's fair share, and a workgroup whose load
+    // is a few heavy pixels is bound by their serial samples.
+    uint32_t group_shift = (uint64_t)pass_groups < 16ull * n_blocks_max ? 4u : 6u;
+    if (const char *e = getenv("RTAMD_PT_GROUP_SHIFT")) { const int v = atoi(e); if (v == 4 || v == 5 || v == 6) group_shift = (uint32_t)v; }
+    const uint32_t sub = 6u - group_shift, groups_per_block = PT_MAX_PATHS >> group_shift;
     const size_t n_slots = (size_t)pass_groups * 64;
     if (scene->pt_slots < n_slots || scene->pt_levels < (size_t)R.ray_depth) {
         if (scene->pt_r0) (void)hipFree(scene->pt_r0);
@@ -764,18 +788,19 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
         HIP_CHECK(hipMalloc((void **)&scene->pt_r0, n_slots * (16 * WF_REC_BASE + 32 * (size_t)R.ray_depth)));
         scene->pt_slots = n_slots; scene->pt_levels = (size_t)R.ray_depth;
     }
-    const size_t group_words = 2 * (size_t)pass_groups + n_blocks_max + 1;
+    const size_t group_words = 2 * ((size_t)pass_groups << sub) + n_blocks_max + 1;
     if (scene->pt_group_words < group_words) {
         if (scene->pt_groups) (void)hipFree(scene->pt_groups);
         scene->pt_groups = nullptr; scene->pt_group_words = 0;
         HIP_CHECK(hipMalloc((void **)&scene->pt_groups, group_words * 4));
         scene->pt_group_words = group_words;
     }
-    uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + pass_groups, *d_ids = d_ofs + n_blocks_max + 1;
+    uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + ((size_t)pass_groups << sub), *d_ids = d_ofs + n_blocks_max + 1;
     dev::PtParams P{};
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
     P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL);
     P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    P.shade_min = 0; // set per pass below
     P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
     P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);
     P.cost_t = 7; P.cost_l = 8;
@@ -800,8 +825,8 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     }
     // two phases when there is something to re-deal: enough samples, and several sub-tiles per workgroup
     const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
-    const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
-    const std::vector<int> stops = phase_stops(two_phase, phase0, R.samples, 2);
+    const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && ((uint64_t)pass_groups << sub) >= 4ull * n_blocks_max;
+    const std::vector<int> stops = phase_stops(two_phase, phase0, R.samples, 2, group_shift < 6u);
     const uint32_t phases = (uint32_t)stops.size();
     if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes * phases) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     dev::WfView W{};
@@ -814,9 +839,13 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
         const uint32_t groups = n_work - first < pass_groups ? n_work - first : pass_groups;
         W.n_slots = groups * 64u;
         W.slot_base = first * 64u;
-        P.n_groups = groups;
-        const uint32_t blocks = groups < n_blocks_max ? groups : n_blocks_max;
+        const uint32_t n_units = groups << sub;   // groups of the deal
+        P.n_groups = n_units; P.group_shift = group_shift;
+        const uint32_t blocks = n_units < n_blocks_max ? n_units : n_blocks_max;
         if (blocks > scene->pt_blocks) scene->pt_blocks = blocks;
+        // a wave turns shader when this many paths wait: a pool of a few hundred paths cannot let its paths wait for a full wave of them
+        // (measured: 1,620 paths per workgroup 32 > 64 > 16; 820 and 200 paths per workgroup 16 > 32 > 64)
+        P.shade_min = env_int("RTAMD_PT_SHADE_MIN", ((uint64_t)groups * 64u) / blocks >= 1536u ? 32 : 16);
         for (uint32_t ph = 0; ph < phases; ph++) {
             RenderView Rp = R;
             Rp.sample_stop = stops[ph];
@@ -824,8 +853,9 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
             P.group_cost = ph + 1 < phases ? d_cost : nullptr;   // every phase but the last measures for the next re-deal
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
+            P.front_first = ph && !getenv("RTAMD_PT_NO_FRONT_FIRST") ? 1u : 0u;
             if (ph == 0) owner.clear(); // the kernel's round-robin deal
-            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream, P.debug, &owner);
+            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, n_units, blocks, groups_per_block, stream, P.debug, &owner);
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
             // kernel variant by the features this render can reach (fewer features, fewer spilled registers): the hw7 integrator has no
@@ -863,11 +893,16 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
 // sample (a wall against the glass bunny), so the deal matters far more than for hw8.
 static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const RenderView &R, uint32_t n_work, hipStream_t stream, bool count, bool time_trace) {
     auto env_int = [](const char *n, int dflt) { const char *e = getenv(n); return e && atoi(e) > 0 ? atoi(e) : dflt; };
-    const uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus);
-    const uint32_t groups_per_block = P6_MAX_PATHS / 64;
-    const uint64_t pass_cap = (uint64_t)n_blocks_max * groups_per_block;
+    const uint32_t n_blocks_max = (uint32_t)env_int("RTAMD_PT_BLOCKS", scene->n_cus * P6_PER_CU); // five 4-wave workgroups per CU
+    const uint64_t pass_cap = (uint64_t)n_blocks_max * (P6_MAX_PATHS / 64);
     const uint32_t passes = (uint32_t)((n_work + pass_cap - 1) / pass_cap);
-    const uint32_t pass_groups = (n_work + passes - 1) / passes;
+    const uint32_t pass_groups = (n_work + passes - 1) / passes;         // 8x8 sub-tiles (64 path slots) per pass
+    // The unit of the deal: an 8x8 sub-tile, or — when a workgroup would hold fewer than sixteen of those (small frames, shards) — a
+    // quarter of one (two pixel rows): a single heavy sub-tile must not outweigh a workgroup's fair share, and a workgroup whose load
+    // is a few heavy pixels is bound by their serial samples.
+    uint32_t group_shift = (uint64_t)pass_groups < 16ull * n_blocks_max ? 4u : 6u;
+    if (const char *e = getenv("RTAMD_PT_GROUP_SHIFT")) { const int v = atoi(e); if (v == 4 || v == 5 || v == 6) group_shift = (uint32_t)v; }
+    const uint32_t sub = 6u - group_shift, groups_per_block = P6_MAX_PATHS >> group_shift;
     const size_t n_slots = (size_t)pass_groups * 64;
     if (scene->pt6_slots < n_slots) {
         if (scene->pt6_r0) (void)hipFree(scene->pt6_r0);
@@ -875,42 +910,47 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
         HIP_CHECK(hipMalloc((void **)&scene->pt6_r0, n_slots * (size_t)P6_REC * sizeof(float4)));
         scene->pt6_slots = n_slots;
     }
-    const size_t group_words = 2 * (size_t)pass_groups + n_blocks_max + 1;
+    const size_t group_words = 2 * ((size_t)pass_groups << sub) + n_blocks_max + 1;
     if (scene->pt_group_words < group_words) {
         if (scene->pt_groups) (void)hipFree(scene->pt_groups);
         scene->pt_groups = nullptr; scene->pt_group_words = 0;
         HIP_CHECK(hipMalloc((void **)&scene->pt_groups, group_words * 4));
         scene->pt_group_words = group_words;
     }
-    uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + pass_groups, *d_ids = d_ofs + n_blocks_max + 1;
+    uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + ((size_t)pass_groups << sub), *d_ids = d_ofs + n_blocks_max + 1;
     dev::PtParams P{};
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
     P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL);
     P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    P.shade_min = 0; // set per pass below
     P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
     P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);
     P.cost_t = 1; P.cost_l = 1;
     P.counters = scene->d_counters;
     P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
-    if (getenv("RTAMD_DEBUG_COUNTERS")) {
-        if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
-        if (n_blocks_max <= PT_DEBUG_BLOCKS) P.debug = scene->d_pt_debug;
-    }
+    // every workgroup leaves its start and exit time (the re-deal measures the workgroups' speeds with them)
+    if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
+    if (n_blocks_max <= PT_DEBUG_BLOCKS) P.debug = scene->d_pt_debug;
     const int phase0 = getenv("RTAMD_PT_PHASE0") ? atoi(getenv("RTAMD_PT_PHASE0")) : R.samples / 16;
-    const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && pass_groups >= 4 * n_blocks_max;
-    const std::vector<int> stops = phase_stops(two_phase, phase0, R.samples, 2);
+    const bool two_phase = !getenv("RTAMD_PT_NO_REBALANCE") && phase0 >= 1 && phase0 < R.samples && ((uint64_t)pass_groups << sub) >= 4ull * n_blocks_max;
+    const std::vector<int> stops = phase_stops(two_phase, phase0, R.samples, 2, group_shift < 6u);
     const uint32_t phases = (uint32_t)stops.size();
     if (time_trace) while (scene->ev_pool.size() < 2 * (size_t)passes * phases) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); scene->ev_pool.push_back(e); }
     dev::W6View W{};
     W.r0 = scene->pt6_r0;
     uint32_t first = 0, launch = 0;
     scene->pt_rebalance_ms = 0; scene->pt_imbalance = 0; scene->pt_blocks = 0;
+    std::vector<uint32_t> owner; // sub-tile -> workgroup of the phase in flight
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t groups = n_work - first < pass_groups ? n_work - first : pass_groups;
         W.slot_base = first * 64u;
-        P.n_groups = groups;
-        const uint32_t blocks = groups < n_blocks_max ? groups : n_blocks_max;
+        const uint32_t n_units = groups << sub;   // groups of the deal
+        P.n_groups = n_units; P.group_shift = group_shift;
+        const uint32_t blocks = n_units < n_blocks_max ? n_units : n_blocks_max;
         if (blocks > scene->pt_blocks) scene->pt_blocks = blocks;
+        // a wave turns shader when this many paths wait: a pool of a few hundred paths cannot let its paths wait for a full wave of them
+        // (measured: 1,620 paths per workgroup 32 > 64 > 16; 820 and 200 paths per workgroup 16 > 32 > 64)
+        P.shade_min = env_int("RTAMD_PT_SHADE_MIN", ((uint64_t)groups * 64u) / blocks >= 1536u ? 32 : 16);
         for (uint32_t ph = 0; ph < phases; ph++) {
             RenderView Rp = R;
             Rp.sample_stop = stops[ph];
@@ -918,11 +958,13 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
             P.group_cost = ph + 1 < phases ? d_cost : nullptr;   // every phase but the last measures for the next re-deal
             P.group_ofs = ph ? d_ofs : nullptr;
             P.group_ids = ph ? d_ids : nullptr;
-            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, groups, blocks, groups_per_block, stream);
+            P.front_first = ph && !getenv("RTAMD_PT_NO_FRONT_FIRST") ? 1u : 0u;
+            if (ph == 0) owner.clear(); // the kernel's round-robin deal
+            if (ph >= 1) redeal_groups(scene, d_cost, d_ofs, d_ids, n_units, blocks, groups_per_block, stream, P.debug, &owner);
             if (P.debug) HIP_CHECK(hipMemsetAsync(scene->d_pt_debug, 0, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long), stream));
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch], stream));
-            if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
-            else hipLaunchKernelGGL(dev::p6_persistent_kernel<false>, dim3(blocks), dim3(PT_THREADS), 0, stream, V, Rp, W, P);
+            if (count) hipLaunchKernelGGL(dev::p6_persistent_kernel<true>, dim3(blocks), dim3(P6_THREADS), 0, stream, V, Rp, W, P);
+            else hipLaunchKernelGGL(dev::p6_persistent_kernel<false>, dim3(blocks), dim3(P6_THREADS), 0, stream, V, Rp, W, P);
             if (time_trace) HIP_CHECK(hipEventRecord(scene->ev_pool[2 * launch + 1], stream));
             launch++;
         }
@@ -1090,7 +1132,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 hipLaunchKernelGGL(dev::render_hw3_kernel, dim3(blocks), dim3(64), 0, stream, scene->viewt, R, txt_tan_fov_y, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
-            } else if (scene->flavor == RT_INTEGRATOR_HW6 && scene->hw6_lds_stack && !(ksel && strcmp(ksel, "mega") == 0) && !getenv("RTAMD_HW6_SCRATCH_STACK")) {
+            } else if (scene->flavor == RT_INTEGRATOR_HW6 && scene->hw6_pt_stack && !(ksel && strcmp(ksel, "mega") == 0) && !getenv("RTAMD_HW6_SCRATCH_STACK")) {
                 // persistent dataflow organisation (device/rt_persistent_hw6.h); RTAMD_KERNEL=mega keeps the per-lane path machine
                 use_persistent6 = true;
                 time_trace = stats != nullptr;
@@ -1131,6 +1173,12 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 for (uint32_t b = 0; b < scene->pt_blocks; b++) { unsigned long long e = dbg[3 * b + 1] - t0; tmin = e < tmin ? e : tmin; tmax = e > tmax ? e : tmax; tsum += (double)e; }
                 fprintf(stderr, "[rtamd] persistent hw6 kernel (last launch): %u workgroups, exit times min / mean / max = %.3f / %.3f / %.3f ms after the first start\n",
                         scene->pt_blocks, tmin * 1e-5, tsum / scene->pt_blocks * 1e-5, tmax * 1e-5);
+                if (const char *dump = getenv("RTAMD_DUMP_WG")) { // diagnostic, as for hw8 (tools/tuning/wg_balance.py)
+                    if (FILE *f = fopen(dump, "w")) {
+                        for (uint32_t b = 0; b < scene->pt_blocks; b++) fprintf(f, "%u %.4f %.4f %llu\n", b, (dbg[3 * b] - t0) * 1e-5, (dbg[3 * b + 1] - t0) * 1e-5, dbg[3 * b + 2]);
+                        fclose(f);
+                    }
+                }
             }
         }
         if (use_persistent6 && h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent hw6 kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");

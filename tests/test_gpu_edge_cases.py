@@ -259,8 +259,8 @@ def test_persistent_pipeline_phases_and_deals_do_not_change_pixels(rt, monkeypat
 
 
 def test_persistent_pipeline_in_several_passes(rt, monkeypatch):
-    """A frame with more path slots than the workgroups' LDS bitmaps hold (1,280 workgroups x 7,168 paths) is rendered in several
-    passes over disjoint slot ranges; with RTAMD_PT_BLOCKS=10 a 400x300 frame (2,080 sub-tiles of 64 slots) already needs two
+    """A frame with more path slots than the workgroups' LDS bitmaps hold (1,280 workgroups x 5,120 paths) is rendered in several
+    passes over disjoint slot ranges; with RTAMD_PT_BLOCKS=14 a 400x300 frame (2,080 sub-tiles of 64 slots) already needs two
     (and each pass its own two phases).  Replay mode, shards and throughput mode (whose stream index comes from the global slot) must not change."""
     import pin_cases
     sd = pin_cases.random_triangle_scene(n=300, seed=12)
@@ -269,7 +269,7 @@ def test_persistent_pipeline_in_several_passes(rt, monkeypatch):
     one, one8, st1 = scene.render(w, h, spp)
     thr1, _, _ = scene.render(w, h, 8, sample_streams=2)
     shard1, _, _ = scene.render(w, h, spp, shard_index=2, shard_count=3, tile=32)
-    monkeypatch.setenv("RTAMD_PT_BLOCKS", "10")
+    monkeypatch.setenv("RTAMD_PT_BLOCKS", "14")
     monkeypatch.setenv("RTAMD_PT_PHASE0", "1")
     two, two8, st2 = scene.render(w, h, spp)
     thr2, _, stt = scene.render(w, h, 8, sample_streams=2)

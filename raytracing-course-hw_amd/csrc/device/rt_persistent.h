@@ -125,6 +125,13 @@ template <class SH> RT_DEV uint32_t pt_slot(const SH &sh, uint32_t l) { const ui
 // taken on SGPRs (scalar branches, wave-uniform by construction — the code under them uses __ballot / __shfl / lane-0 atomics).
 RT_DEV int pt_count(const int *p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 
+// Lanes that must wait at a leaf before the wave runs its triangle tests: a share (leaf_batch >> 16, in 1/256) of the active lanes, at most
+// leaf_batch & 255.  Plain integer arithmetic on purpose: min() of an int and __popcll's result picks the double overload.
+RT_DEV int pt_leaf_batch(int leaf_batch, unsigned long long m_active) {
+    const int cap = leaf_batch & 255, share = ((int)__popcll(m_active) * (leaf_batch >> 16) + 255) >> 8;
+    return share < cap ? share : cap;
+}
+
 // Number of set bits of a wave mask below this lane (v_mbcnt: no 64-bit lane mask in registers).
 RT_DEV uint32_t pt_rank_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -252,7 +259,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         }
         const unsigned long long m_active = __ballot(active);
         if (!m_active) break;
-        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
@@ -381,7 +388,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         }
         const unsigned long long m_active = __ballot(active);
         if (!m_active) break;
-        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;

@@ -317,7 +317,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         }
         const unsigned long long m_active = __ballot(active);
         if (!m_active) break;
-        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
@@ -376,23 +376,55 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris) {
     const int lane = threadIdx.x & 63;
     bool active = false, refill_ok = true, many = false, fragile = false; // fragile: a hit at a box boundary, the sum goes to the exact walk
-    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, idx0 = 0, idx1 = 0; // fin: the lane's finished, unpublished path; bit 31 = it goes to the slow role
+    uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, idx0 = 0, idx1 = 0, idx2 = 0, idx3 = 0; // fin: the lane's finished, unpublished path; bit 31 = it goes to the slow role
     int sp = 0, k = 0;
     uint32_t steps = 0;
-    float term0 = 0.f, term1 = 0.f;
+    float term0 = 0.f, term1 = 0.f, term2 = 0.f, term3 = 0.f;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayInv ray = make_ray_inv(o, d);
+    // where the lights x < y of the reference order separate in the reference's light tree (SceneView6::light_sep, see p6_merge_hits)
+    auto sep = [&](uint32_t x, uint32_t y) {
+        const uint32_t lv = 31u - (uint32_t)__clz((int)(y - x));
+        const uint32_t row = lv * S.n_lights; // 32-bit: the table has fewer than 2^32 entries (levels x lights)
+        const uint16_t m0 = S.light_sep[row + x], m1 = S.light_sep[row + (y - (1u << lv))];
+        return (uint32_t)(m0 < m1 ? m0 : m1);
+    };
     auto finish = [&]() {
         active = false;
         if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_LIGHT_STEP);
-        if (fragile) { // the hits go along (also when there are fewer than three), the slow role adds them with the reference's box tests
+        if (fragile) { // the hits go along (also when there are fewer than five), the slow role adds them with the reference's box tests
             float2 *h = reinterpret_cast<float2 *>(p6_rec(W, slot) + 48);
-            if (k >= 1 && k <= 2) h[0] = make_float2(__uint_as_float(idx0), term0);
-            if (k == 2) h[1] = make_float2(__uint_as_float(idx1), term1);
+            if (k >= 1 && k <= 4) h[0] = make_float2(__uint_as_float(idx0), term0);
+            if (k >= 2 && k <= 4) h[1] = make_float2(__uint_as_float(idx1), term1);
+            if (k >= 3 && k <= 4) h[2] = make_float2(__uint_as_float(idx2), term2);
+            if (k == 4) h[3] = make_float2(__uint_as_float(idx3), term3);
             reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k | 0x80000000u; fin = l | 0x80000000u; return;
         }
         if (many) { reinterpret_cast<uint32_t *>(p6_rec(W, slot) + 7)[0] = (uint32_t)k; fin = l | 0x80000000u; return; }
-        const float v = k == 0 ? 0.f : (k == 1 ? term0 : term0 + term1);
+        float v = k == 0 ? 0.f : (k == 1 ? term0 : term0 + term1);
+        if (k == 3) {
+            // three hits (the commonest case beyond two) are added here and now, in the reference's association: sorted by reference index
+            // a < b < c, the pair that separates deeper in the reference tree is added first — (a + b) + c when sep(a,b) > sep(b,c), else
+            // a + (b + c): p6_merge_hits for k = 3 without the trip through the slow role's queue
+            uint32_t ia = idx0, ib = idx1, ic = idx2; float ta = term0, tb = term1, tc = term2;
+            if (ia > ib) { const uint32_t ti = ia; ia = ib; ib = ti; const float tt = ta; ta = tb; tb = tt; }
+            if (ib > ic) { const uint32_t ti = ib; ib = ic; ic = ti; const float tt = tb; tb = tc; tc = tt; }
+            if (ia > ib) { const uint32_t ti = ia; ia = ib; ib = ti; const float tt = ta; ta = tb; tb = tt; }
+            v = sep(ia, ib) > sep(ib, ic) ? (ta + tb) + tc : ta + (tb + tc);
+        }
+        if (k == 4) {
+            // four hits — a ray through two closed shells of light triangles: 61 % of the sums with more than two hits on practice6_2 — the
+            // same way: sorted a < b < c < e with separation depths d1, d2, d3, the operator-precedence evaluation of p6_merge_hits
+            // (a deeper separation binds first, equal depths associate to the right) spelled out in its five outcomes
+            uint32_t i0 = idx0, i1 = idx1, i2 = idx2, i3 = idx3; float t0 = term0, t1 = term1, t2 = term2, t3 = term3;
+#define P6_CSWAP(ia, ib, ta, tb) if (ia > ib) { const uint32_t ti_ = ia; ia = ib; ib = ti_; const float tt_ = ta; ta = tb; tb = tt_; }
+            P6_CSWAP(i0, i1, t0, t1) P6_CSWAP(i2, i3, t2, t3) P6_CSWAP(i0, i2, t0, t2) P6_CSWAP(i1, i3, t1, t3) P6_CSWAP(i1, i2, t1, t2)
+#undef P6_CSWAP
+            const uint32_t d1 = sep(i0, i1), d2 = sep(i1, i2), d3 = sep(i2, i3);
+            if (d1 > d2) v = d2 > d3 ? ((t0 + t1) + t2) + t3 : (t0 + t1) + (t2 + t3);
+            else if (d2 > d3) v = d1 > d3 ? (t0 + (t1 + t2)) + t3 : t0 + ((t1 + t2) + t3);
+            else v = t0 + (t1 + (t2 + t3));
+        }
         reinterpret_cast<float *>(p6_rec(W, slot) + 4)[3] = v;
         fin = l;
     };
@@ -426,7 +458,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         }
         const unsigned long long m_active = __ballot(active);
         if (!m_active) break;
-        const int lb = min(P.leaf_batch & 255, (__popcll(m_active) * (P.leaf_batch >> 16) + 255) >> 8);
+        const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
@@ -466,9 +498,11 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                         }
                         if (k == 0) { term0 = term; idx0 = T.ref_index; }
                         else if (k == 1) { term1 = term; idx1 = T.ref_index; }
-                        else {
+                        else if (k == 2) { term2 = term; idx2 = T.ref_index; }
+                        else if (k == 3) { term3 = term; idx3 = T.ref_index; }
+                        else { // five or more: the hits go to the record for the slow role
                             float2 *h = reinterpret_cast<float2 *>(p6_rec(W, slot) + 48);
-                            if (k == 2) { h[0] = make_float2(__uint_as_float(idx0), term0); h[1] = make_float2(__uint_as_float(idx1), term1); }
+                            if (k == 4) { h[0] = make_float2(__uint_as_float(idx0), term0); h[1] = make_float2(__uint_as_float(idx1), term1); h[2] = make_float2(__uint_as_float(idx2), term2); h[3] = make_float2(__uint_as_float(idx3), term3); }
                             if (k < RT6_MAX_LIGHT_HITS) h[k] = make_float2(__uint_as_float(T.ref_index), term);
                             many = true;
                         }
@@ -489,40 +523,51 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
 // that separate deepest in the reference tree (SceneView6::light_sep; inside a leaf the pseudo depths give ((a + b) + c)).  That is
 // an operator-precedence evaluation with the separation depth as the precedence, done in place in the lane's LDS stack column:
 // words 0..15 hold the terms and then the value stack, words 16..31 the light indices and then the depth stack. ---------------------
-RT_DEV float p6_merge_hits(const SceneView6 &S, const float2 *h, int k, uint32_t (*col)[64]) { // k <= P6_MERGE_HITS
-    const int lane = threadIdx.x & 63;
-    const int I = P6_MERGE_HITS;                              // words 0..I-1: terms / value stack; words I..: light indices / depth stack
+// vals: k words (terms, then the value stack); ids: k + 1 words (light indices, then the depth stack)
+template <class AV, class AI>
+RT_DEV float p6_merge_hits_in(const SceneView6 &S, const float2 *h, int k, AV vals, AI ids) {
     for (int i = 0; i < k; i++) { // insertion sort by the reference's light index
         const float2 e = h[i];
         const uint32_t id = __float_as_uint(e.x);
         int j = i - 1;
-        while (j >= 0 && col[I + j][lane] > id) { col[I + 1 + j][lane] = col[I + j][lane]; col[j + 1][lane] = col[j][lane]; j--; }
-        col[I + 1 + j][lane] = id; col[j + 1][lane] = __float_as_uint(e.y);
+        while (j >= 0 && ids[j] > id) { ids[j + 1] = ids[j]; vals[j + 1] = vals[j]; j--; }
+        ids[j + 1] = id; vals[j + 1] = __float_as_uint(e.y);
     }
     const uint32_t nl = S.n_lights;
-    int vs = 1, os = 0;                                   // value stack: words 0..vs-1; depth stack: words I..I+os-1
-    uint32_t prev = col[I][lane];
+    int vs = 1, os = 0;                                   // value stack: vals[0..vs-1]; depth stack: ids[0..os-1]
+    uint32_t prev = ids[0];
     for (int i = 1; i < k; i++) {
-        const uint32_t id = col[I + i][lane];
-        const float term = __uint_as_float(col[i][lane]);
+        const uint32_t id = ids[i];
+        const float term = __uint_as_float(vals[i]);
         const uint32_t len = id - prev, lv = 31u - (uint32_t)__clz((int)len);
-        const uint16_t m0 = S.light_sep[(size_t)lv * nl + prev], m1 = S.light_sep[(size_t)lv * nl + (id - (1u << lv))];
+        const uint32_t row = lv * nl;
+        const uint16_t m0 = S.light_sep[row + prev], m1 = S.light_sep[row + (id - (1u << lv))];
         const uint32_t depth = m0 < m1 ? m0 : m1;          // where the hits prev and id separate
-        while (os > 0 && col[I - 1 + os][lane] > depth) {  // the groups on the stack that separate deeper are complete: fold them
-            const float b = __uint_as_float(col[vs - 1][lane]), a = __uint_as_float(col[vs - 2][lane]);
-            col[vs - 2][lane] = __float_as_uint(a + b);
+        while (os > 0 && ids[os - 1] > depth) {            // the groups on the stack that separate deeper are complete: fold them
+            const float b = __uint_as_float(vals[vs - 1]), a = __uint_as_float(vals[vs - 2]);
+            vals[vs - 2] = __float_as_uint(a + b);
             vs--; os--;
         }
-        col[I + os][lane] = depth; os++;                   // os <= i - 1 < the index words already consumed: never overwrites an unread index
-        col[vs][lane] = __float_as_uint(term); vs++;
+        ids[os] = depth; os++;                             // os <= i - 1 < the index words already consumed: never overwrites an unread index
+        vals[vs] = __float_as_uint(term); vs++;
         prev = id;
     }
     while (os > 0) {
-        const float b = __uint_as_float(col[vs - 1][lane]), a = __uint_as_float(col[vs - 2][lane]);
-        col[vs - 2][lane] = __float_as_uint(a + b);
+        const float b = __uint_as_float(vals[vs - 1]), a = __uint_as_float(vals[vs - 2]);
+        vals[vs - 2] = __float_as_uint(a + b);
         vs--; os--;
     }
-    return __uint_as_float(col[0][lane]);
+    return __uint_as_float(vals[0]);
+}
+struct P6Column { // a lane's own stack column, words first .. : indexable
+    uint32_t (*col)[64]; int first, lane;
+    RT_DEV uint32_t &operator[](int i) const { return col[first + i][lane]; }
+};
+RT_DEV float p6_merge_hits(const SceneView6 &S, const float2 *h, int k, uint32_t (*col)[64]) { // k <= P6_MERGE_HITS, in the lane's own column
+    P6Column vals, ids;
+    vals.col = col; vals.first = 0; vals.lane = threadIdx.x & 63;
+    ids.col = col; ids.first = P6_MERGE_HITS; ids.lane = vals.lane;
+    return p6_merge_hits_in(S, h, k, vals, ids);
 }
 
 // ---- exact role: BVH::intersect_ of hw6 (bvh.h, identical to hw8's) over the reference's own tree with the reference's box test, as an
@@ -743,7 +788,8 @@ RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &
                     v = ref_light_pdf_sum6_along(S, lx, ld, hit_idx, hit_term, k, f_node, f_lo, f_hi, f_val);
                 }
                 n_xlight++;
-            } else v = light_pdf_sum6(S, lx, ld, sl); // more than P6_MERGE_HITS hits
+            } else if (k <= RT6_MAX_LIGHT_HITS) v = p6_merge_hits_in(S, reinterpret_cast<const float2 *>(r + 48), k, sl.at(0), sl.at(RT6_MAX_LIGHT_HITS)); // more hits than a column takes
+            else v = light_pdf_sum6(S, lx, ld, sl);       // more hits than the record holds: the plain reference-order walk
             reinterpret_cast<float *>(r + 4)[3] = v;
         }
     }
@@ -858,6 +904,7 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
             if (got != PT_NONE) {
                 float4 *r = p6_rec(W, pt_slot(sh, got));
                 const uint32_t kw = reinterpret_cast<const uint32_t *>(r + 7)[0];
+                if (COUNT && P.counters) atomicAdd(&P.counters[32 + ((kw & 0x7FFFFFFFu) < 15u ? (kw & 0x7FFFFFFFu) : 15u)], 1ull); // histogram of the hit counts that reach the slow role
                 if ((kw >> 31) || kw > (uint32_t)P6_MERGE_HITS) batch = true;
                 else reinterpret_cast<float *>(r + 4)[3] = p6_merge_hits(S, reinterpret_cast<const float2 *>(r + 48), (int)kw, stack);
             }

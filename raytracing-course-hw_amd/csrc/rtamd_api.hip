@@ -1161,6 +1161,9 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             fprintf(stderr, "[rtamd] persistent hw6 pipeline: %u launches; re-deal %.2f ms on the host (slowest workgroup / mean under the round-robin deal: %.3f); light sums through the slow role %llu of %llu; exact closest-hit walks %llu of %llu, exact light sums %llu\n",
                     scene->pt_launches, scene->pt_rebalance_ms, scene->pt_imbalance, h_cnt[13], h_cnt[1], h_cnt[12], h_cnt[0], h_cnt[11]);
             if (count) {
+                fprintf(stderr, "[rtamd] persistent hw6 kernel, light sums in the slow role by number of hits (0..14, 15+):");
+                for (int b = 0; b < 16; b++) fprintf(stderr, " %llu", h_cnt[32 + b]);
+                fprintf(stderr, "\n");
                 const double tt = (double)(h_cnt[16] + h_cnt[17] + h_cnt[18] + h_cnt[19] + h_cnt[20]);
                 fprintf(stderr, "[rtamd] persistent hw6 kernel, wave time by role: closest-hit walks %.1f %%, light walks %.1f %%, shading %.1f %%, slow light sums %.1f %%, idle %.1f %%\n",
                         100 * h_cnt[16] / tt, 100 * h_cnt[17] / tt, 100 * h_cnt[18] / tt, 100 * h_cnt[19] / tt, 100 * h_cnt[20] / tt);

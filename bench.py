@@ -185,7 +185,7 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H, SPP = wl["width"], wl["height"], (args.spp if args.spp > 0 else wl["spp"])
     base_w, base_h = W, H
-    scaling = args.scaling if world > 1 else "weak"  # at N = 1 the two coincide; "weak" = per-GPU work is what the workload names
+    scaling = args.scaling if world > 1 else "n/a"  # at N = 1 there is nothing to scale: the workload is the named frame
     if world > 1 and args.scaling == "weak":
         # Weak scaling: every GPU keeps one base frame's worth of pixels; the frame grows by sqrt(N) per side.
         # A pixel's samples are serial in replay mode, so pixels are the only axis that can grow.
@@ -349,6 +349,16 @@ def main():
                     roofline["traffic_source"] = tj.get("source", "profiles/traffic_latest.json")
             except (OSError, ValueError, KeyError):
                 pass
+        # What the kernel is really limited by (the working set is cache-resident, "hbm" above is the nominal roofline of SURVEY 8(d)):
+        # the SQ / TCC counters of the same profiling run, condensed by tools/pmc_limiter.py into profiles/limiter_latest.json.
+        lpath = os.path.join(ROOT, "profiles", "limiter_latest.json")
+        if os.path.exists(lpath):
+            try:
+                lj = json.load(open(lpath))
+                if lj.get("workload") == args.workload and lj.get("kernel") == roofline["kernel"]:
+                    roofline["limiter"] = lj
+            except (OSError, ValueError):
+                pass
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(args, rt, np, sd, W, H, SPP)
@@ -395,6 +405,9 @@ def main():
                 vst = plain.render_device(params, out_rgb.data_ptr(), out_rgb8.data_ptr())
                 plain.close()
                 variants["persistent_pipeline_without_exactness_gate_msamples_per_s"] = round(vst.samples / vst.kernel_ms / 1e3, 1)
+                gated = min(kernel_ms) if kernel_ms else None       # the timed renders of this run (kernel time), same box
+                if gated:
+                    variants["exactness_gate_cost_pct"] = round(100.0 * (gated / vst.kernel_ms - 1.0), 2)  # persistent pipeline, kernel time with the gate vs without
                 variants["note"] = "untimed single renders (kernel time) on the same box; the headline runs with the gate: every pixel the reference's"
                 base["config"]["without_exactness_gate"] = variants
             except Exception as e:

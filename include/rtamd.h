@@ -204,7 +204,8 @@ typedef struct rt_stats {
                                           hits went through the exactness gate, the doubtful ones through the reference-exact walk);
                                           0 = the answer of the walkers' padded boxes stood (RTAMD_NO_EXACT_BOXES, RT_BUILD_DEVICE_BVH,
                                           RTAMD_KERNEL=wavefront|mega, or a tree beyond the gated pipelines' limits): a pixel in ~1e5 may
-                                          then differ from the reference's.  0 for the other integrators (nothing to gate). */
+                                          then differ from the reference's.  hw5: always 1 (its kernel walks the reference's trees with the reference's own box
+                                          test).  0 for hw1..hw4 (no boxes: nothing to decide). */
     uint64_t exact_closest_hits, exact_light_sums; /* RT_PIPELINE_PERSISTENT: queries re-walked with the reference's own box
                                                       arithmetic (hw8/src/primitives.cpp:29-53,163-165) because the fast walk's
                                                       answer was not robust against it */

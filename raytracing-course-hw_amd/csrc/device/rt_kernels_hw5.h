@@ -10,6 +10,7 @@
 #pragma once
 #include "rt_types_hw5.h"
 #include "rt_kernels_hw4.h"
+#include "rt_exact.h"
 
 namespace rtamd {
 namespace dev {
@@ -52,8 +53,7 @@ RT_DEV bool fig_hit5(const FigRegs &F, F3 o, F3 d, float &t, F3 &norma, bool &in
 
 struct Hit5 { int idx; float t; F3 n; bool inside; };
 // Scene::intersect (scene.cpp:25-45): planes first (strict '<' keeps the first), then the BVH, whose result replaces
-// the plane hit only when strictly nearer.  Inside the BVH the reference visits figures in index order and replaces on
-// strict '<' (bvh.h:111-140): smallest t, equal t -> lowest index; this walk is near-first, so the index rule is explicit.
+// the plane hit only when strictly nearer.
 RT_DEV Hit5 closest_hit5(const SceneView5 &S, F3 o, F3 d, uint32_t *stack) {
     Hit5 best; best.idx = -1; best.t = RT_T_MAX; best.n = f3(0.f, 0.f, 0.f); best.inside = false;
     for (uint32_t i = S.n_nonplanes; i < S.n_figs; i++) {
@@ -62,38 +62,34 @@ RT_DEV Hit5 closest_hit5(const SceneView5 &S, F3 o, F3 d, uint32_t *stack) {
         if (fig_hit5(F, o, d, t, n, inside) && (best.idx < 0 || t < best.t)) { best.idx = (int)i; best.t = t; best.n = n; best.inside = inside; }
     }
     if (S.n_nonplanes == 0) return best;
-    const bool plane_best = best.idx >= 0;
-    bool bvh_best = false;
-    RayInv ray = make_ray_inv(o, d);
+    // BVH::intersect_ (bvh.h:111-141) with the reference's own box test on its unpadded boxes (AABB::intersect, primitives.cpp:221-223 ->
+    // intersectBoxAndRay, :92-116: ref_box_test of rt_exact.h is the same code), as an iterative left-first walk.  The recursion's
+    // `curBest` at a node is the smallest t of the plane hit and of everything found before the node in this order (every level hands
+    // its left result on to its right child), so one running value prunes (`curBest < t_box && !inside`); the result is the first
+    // figure with the smallest t (a leaf and a parent both replace on strict '<' only), and it replaces the plane hit when strictly nearer.
+    // hw5's scenes are a handful of figures: the exact test at every node costs nothing that matters, and no gate is needed.
+    bool have_cur = best.idx >= 0;
+    float cur_best = best.t;
+    Hit5 bvh; bvh.idx = -1; bvh.t = RT_T_MAX; bvh.n = f3(0.f, 0.f, 0.f); bvh.inside = false;
     int sp = 0;
     uint32_t cur = 0;
     for (;;) {
-        if (!(cur & RT_LEAF_BIT)) {
-            const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
-            float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
-            float n0, n1;
-            bool h0 = slab_test(lo0, hi0, ray, best.t, n0);
-            bool h1 = slab_test(lo1, hi1, ray, best.t, n1);
-            uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-            if (h0 & h1) { bool swap = n1 < n0; stack[sp++] = swap ? c0 : c1; cur = swap ? c1 : c0; continue; }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else if (cur != RT_EMPTY_LEAF) {
-            uint32_t i = cur & ~RT_LEAF_BIT;
-            for (;;) {
-                FigRegs F = load_fig5(S.figs + i);
-                float t; F3 n; bool inside;
-                if (fig_hit5(F, o, d, t, n, inside)) {
-                    bool better = bvh_best ? (t < best.t || (t == best.t && (int)i < best.idx)) : (!plane_best || t < best.t);
-                    if (better) { best.idx = (int)i; best.t = t; best.n = n; best.inside = inside; bvh_best = true; }
+        const RefNodeView n = load_ref_node(S.ref_nodes + cur);
+        float tb; bool inside_box;
+        if (ref_box_test(n.mn, n.mx, o, d, tb, inside_box) && !(have_cur && cur_best < tb && !inside_box)) {
+            if (n.left == 0) {
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    FigRegs F = load_fig5(S.figs + i);
+                    float t; F3 nn; bool inside;
+                    if (fig_hit5(F, o, d, t, nn, inside) && (bvh.idx < 0 || t < bvh.t)) { bvh.idx = (int)i; bvh.t = t; bvh.n = nn; bvh.inside = inside; }
                 }
-                if (F.last) break;
-                i++;
-            }
+                if (bvh.idx >= 0 && (!have_cur || bvh.t < cur_best)) { have_cur = true; cur_best = bvh.t; }
+            } else if (sp < RT5_STACK) { stack[sp++] = n.right; cur = n.left; continue; }
         }
         if (sp == 0) break;
         cur = stack[--sp];
     }
+    if (bvh.idx >= 0 && (best.idx < 0 || bvh.t < best.t)) best = bvh;
     return best;
 }
 
@@ -119,7 +115,7 @@ RT_DEV float light_pdf_one5(const FigRegs &F, F3 x, F3 d) {
 // FiguresMix::getTotalPdf, distributions.h:256-274: total(left) + total(right), sequential sum inside a leaf — the same
 // tree of float additions replayed with TODO(child) / ADD(partial) frames (see light_pdf_sum in rt_device.h).
 RT_DEV float light_pdf_sum5(const SceneView5 &S, F3 x, F3 d, uint32_t *stack) {
-    RayInv ray = make_ray_inv(x, d);
+    // the reference's own box test at every node (distributions.h:256-262): a failed box contributes 0 whatever lies below it
     int sp = 0;
     unsigned long long addmask = 0;
     uint32_t cur = 0;
@@ -127,31 +123,19 @@ RT_DEV float light_pdf_sum5(const SceneView5 &S, F3 x, F3 d, uint32_t *stack) {
     float v = 0.f;
     for (;;) {
         if (descending) {
-            if (cur & RT_LEAF_BIT) {
+            const RefNodeView n = load_ref_node(S.ref_light_nodes + cur);
+            float tb; bool inside_box;
+            if (!ref_box_test(n.mn, n.mx, x, d, tb, inside_box)) { v = 0.f; descending = false; }
+            else if (n.left == 0) {
                 float result = 0.f;
-                if (cur != RT_EMPTY_LEAF) {
-                    uint32_t i = cur & ~RT_LEAF_BIT;
-                    for (;;) {
-                        FigRegs F = load_fig5(S.lights + i);
-                        result += light_pdf_one5(F, x, d);
-                        if (F.last) break;
-                        i++;
-                    }
+                for (uint32_t i = n.first; i < n.last; i++) {
+                    FigRegs F = load_fig5(S.lights + i);
+                    result += light_pdf_one5(F, x, d);
                 }
                 v = result;
                 descending = false;
-                continue;
-            }
-            const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
-            float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
-            float n0, n1;
-            bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
-            bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
-            uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-            if (h0 & h1) { addmask &= ~(1ull << sp); stack[sp++] = c1; cur = c0; }
-            else if (h0) cur = c0;
-            else if (h1) cur = c1;
-            else { v = 0.f; descending = false; }
+            } else if (sp < RT5_STACK) { addmask &= ~(1ull << sp); stack[sp++] = n.right; cur = n.left; }
+            else { v = 0.f; descending = false; } // deeper than the host admits (checked there)
         } else {
             if (sp == 0) break;
             --sp;

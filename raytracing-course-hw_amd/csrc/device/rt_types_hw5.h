@@ -22,6 +22,8 @@ struct SceneView5 {
     const GpuNode *nodes;        // reference topology over figs[0, n_nonplanes)
     const GpuFig5 *figs;         // the reference's figure order after Scene::initBVH: BVH figures, then the planes
     const GpuNode *light_nodes;  // reference topology over the light list (fixes the order of the pdf additions)
+    const GpuRefNode *ref_nodes, *ref_light_nodes; // the same two trees with the reference's UNPADDED boxes: what the kernel walks, with the
+                                 // reference's own box test and pruning rule (hw5/src/include/bvh.h:111-141, primitives.cpp:92-116,221-223)
     const GpuFig5 *lights;       // FiguresMix::figures_ order
     uint32_t n_figs, n_nonplanes, n_lights;
     float cam_pos[3], cam_right[3], cam_up[3], cam_fwd[3];

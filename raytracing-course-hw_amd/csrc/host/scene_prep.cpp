@@ -647,6 +647,8 @@ void prepare_scene_hw5(const rt_scene_desc &d, PreparedScene5 &out) {
     std::vector<uint32_t> scene_leaf_last, light_leaf_last;
     encode_tree(scene_builder.nodes, out.nodes, scene_leaf_last);
     encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last);
+    encode_ref_tree(scene_builder.nodes, out.ref_nodes);
+    encode_ref_tree(light_builder.nodes, out.ref_light_nodes);
     auto make = [&](uint32_t src) {
         const rt_primitive &f = d.primitives[src];
         GpuFig5 g;

@@ -70,6 +70,7 @@ void prepare_scene_hw6(const rt_scene_desc &desc, PreparedScene6 &out, bool tree
 // (hw5/src/scene.cpp:8-23, hw5/src/include/distributions.h:180-198), both trees in the reference's topology.
 struct PreparedScene5 {
     std::vector<GpuNode> nodes, light_nodes;
+    std::vector<GpuRefNode> ref_nodes, ref_light_nodes; // the reference's own trees with their unpadded boxes: what the hw5 kernel walks (reference-exact box decisions)
     std::vector<GpuFig5> figs, lights;
     std::vector<uint32_t> figure_order, light_order; // reference orders -> LOAD index
     uint32_t n_nonplanes = 0, bvh_depth = 0, light_bvh_depth = 0;

@@ -207,6 +207,8 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
                 V5.nodes = upload(P5.nodes, bytes); s->allocations.push_back((void *)V5.nodes);
                 V5.figs = upload(P5.figs, bytes); s->allocations.push_back((void *)V5.figs);
                 V5.light_nodes = upload(P5.light_nodes, bytes); s->allocations.push_back((void *)V5.light_nodes);
+                V5.ref_nodes = upload(P5.ref_nodes, bytes); s->allocations.push_back((void *)V5.ref_nodes);
+                V5.ref_light_nodes = upload(P5.ref_light_nodes, bytes); s->allocations.push_back((void *)V5.ref_light_nodes);
                 if (!P5.lights.empty()) { V5.lights = upload(P5.lights, bytes); s->allocations.push_back((void *)V5.lights); }
                 V5.n_figs = (uint32_t)P5.figs.size(); V5.n_nonplanes = P5.n_nonplanes; V5.n_lights = (uint32_t)P5.lights.size();
                 for (int k = 0; k < 3; k++) {
@@ -1246,7 +1248,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->total_ms = now_ms() - t0;
             stats->launches = launches;
             stats->pipeline = (uint32_t)scene->pipeline;
-            stats->reference_exact = use_persistent6 ? (scene->view6.exact_boxes ? 1u : 0u)
+            stats->reference_exact = p->integrator == RT_INTEGRATOR_HW5 ? 1u : use_persistent6 ? (scene->view6.exact_boxes ? 1u : 0u)
                                      : ((scene->flavor == RT_INTEGRATOR_HW8 && (use_persistent || (use_wavefront && blocks)) && V8.exact_boxes) ? 1u : 0u);
             if (use_persistent || use_persistent6) {
                 double sum = 0;

@@ -42,6 +42,15 @@ def test_headline_workload_strong_keeps_the_1080p_frame():
     assert d["config"]["width"] == 1920 and d["config"]["height"] == 1080 and d["scaling"] == "strong" and d["config"]["gathered_frame_ok"] is True
 
 
+def test_eight_ranks_gather_the_3840x2160_frame_of_config_4():
+    """BASELINE.json configs[4]'s layout — 3840x2160 cut into 32x32 tiles dealt round-robin to EIGHT ranks (1,013 or 1,012 tiles each, the
+    last tile row cut by the frame edge), one gather to rank 0 — with fake renders over gloo: every tile of every rank must land where
+    it belongs.  (The real render of one such shard is a -m gpu test; eight physical GPUs have never been available to this repo.)"""
+    d = _run(["--workload", "synth_room_v1_3840x2160x1024"], 8)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["width"] == 3840 and d["config"]["height"] == 2160
+    assert d["config"]["gathered_frame_ok"] is True and "FAKE RENDER" in d["metric"]
+
+
 def test_failure_of_the_ranks_is_the_parents_exit_code():
     env = dict(os.environ, RTAMD_BENCH_FAKE_RENDER="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):

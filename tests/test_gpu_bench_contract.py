@@ -21,7 +21,7 @@ def test_bench_json_line_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] == "n/a" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "NOT the headline config" in d["metric"] and d["config"]["workload"].startswith("synth_room_small")
     assert d["value"] > 0 and abs(d["value"] - 320 * 180 * 16 / (d["ms_per_step"] * 1e3)) < 0.02 * d["value"]
     r = d["roofline"]

@@ -71,3 +71,23 @@ def test_txt_scene_with_triangles_is_refused_by_older_integrators(rt):
     with pytest.raises(rt.RtError):
         scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW3, ray_depth=depth)
     scene.close()
+
+
+def test_hw5_emissive_point_light_box_rounding(rt, tmp_path):
+    """An emissive zero-area TRIANGLE makes FiguresMix::sample aim rays EXACTLY at a vertex, i.e. through the corners of the boxes of the
+    reference's light tree and scene tree — where its own slab test (six divisions on the re-centred box, hw5/src/primitives.cpp:92-116,
+    221-223) decides by one ulp.  The hw5 kernel walks the reference's trees with that very test and pruning rule (bvh.h:111-141), so
+    the frame must be the oracle's — pinned bit-exact to the compiled reference, tests/golden/pins_hw5_* — bit for bit."""
+    src = open(os.path.join(TXT, "hw5_mixed_figures.txt")).read()
+    extra = ("NEW_PRIMITIVE\nTRIANGLE 0.2 0.1 -0.3 0.2 0.1 -0.3 0.2 0.1 -0.3\nPOSITION 0.4 2.1 0.8\nROTATION 0.1 0.2 0.05 0.97\nEMISSION 3 3 2\n"
+             "NEW_PRIMITIVE\nTRIANGLE -0.4 0.0 0.1 0.5 0.05 0.1 0.0 0.6 -0.2\nPOSITION -0.5 1.5 1.0\nROTATION 0 0.1 0 0.995\nEMISSION 1 2 3\n")
+    path = str(tmp_path / "hw5_point_light.txt")
+    open(path, "w").write(src + extra)
+    sd, w, h, spp, depth = rt.load_txt(path, rt.RT_INTEGRATOR_HW5)
+    scene = rt.Scene(sd)
+    rgb, _, _ = scene.render(w, h, 12, integrator=rt.RT_INTEGRATOR_HW5, ray_depth=depth, want_rgb8=False)
+    scene.close()
+    ref, _ = oracle_lib.Hw5Oracle(sd).render(w, h, 12, depth)
+    differing = int((rgb.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
+    print(f"hw5 emissive point light {w}x{h}x12: {differing} pixels differ from the oracle in any bit, non-finite pixels {int((~np.isfinite(ref)).any(axis=2).sum())}")
+    assert np.array_equal(rgb, ref, equal_nan=True)

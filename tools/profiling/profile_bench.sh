@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -17,6 +17,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_tcc -- python3 bench.py --steps 1 --warmup 0 --spp 16 --no-cpu-baseline > $O/pmc_tcc.log 2>&1
 mkdir -p $O/pmc_traffic && cp -r $O/pmc_fetch $O/pmc_write $O/pmc_traffic/
 python3 tools/pmc_traffic.py $O/pmc_traffic synth_room_v1_1920x1080x256 $O/traffic_latest.json pt_persistent_kernel 1 256
+mkdir -p $O/pmc_lim && cp -r $O/pmc_sq $O/pmc_tcc $O/pmc_lim/
+python3 tools/pmc_limiter.py $O/pmc_lim synth_room_v1_1920x1080x256 $O/limiter_latest.json pt_persistent_kernel 5 || echo "limiter summary failed"
+rm -rf $O/pmc_lim
 mkdir -p $O/pmc && cp -r $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_tcc $O/pmc/ 2>/dev/null || true
 python3 tools/summarize_rocprof.py $O/stats $O/${TAG}_final_rocprof.txt "bench.py --steps 2 --warmup 1 --no-cpu-baseline (1920x1080x256; persistent pipeline: two launches per frame)" > /dev/null
 python3 tools/summarize_rocprof.py $O/pmc $O/${TAG}_final_pmc.txt "FETCH_SIZE / WRITE_SIZE passes: bench.py --steps 1 --warmup 0 (full 256 spp, the counting side-render at 4 spp included); SQ / TCC passes: --spp 16" > /dev/null

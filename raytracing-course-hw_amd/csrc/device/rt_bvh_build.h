@@ -25,7 +25,10 @@ namespace dev {
 
 #define BVB_BINS 16
 #define BVB_BIN_WORDS 7                      // count, ~ord(lo.xyz), ord(hi.xyz)
-#define BVB_NODE_BIN_WORDS (3 * BVB_BINS * BVB_BIN_WORDS)
+// per open node: 3 x 16 centroid bins, then two pseudo bins whose count words hold how many of the node's primitives have index-hash
+// bit 0 / 1 at the node's depth: the split of last resort when no plane separates the centroids (bvb_hash_bit)
+#define BVB_HASH_BINS (3 * BVB_BINS * BVB_BIN_WORDS)
+#define BVB_NODE_BIN_WORDS (BVB_HASH_BINS + 2 * BVB_BIN_WORDS)
 #define BVB_MAX_DEPTH 28                     // upper bound of BvbView::max_depth (leaves at depth <= max_depth: a traversal stack of that many entries is enough)
 #define BVB_MAX_LEAF 8                       // above this a node is split even when the SAH says "leaf"
 #define BVB_NONE 0xFFFFFFFFu
@@ -78,6 +81,14 @@ __device__ __forceinline__ int bvb_bin(float c2, float clo2, float chi2) {
     if (!(e > 0.f)) return 0;
     const int b = (int)((c2 - clo2) * ((float)BVB_BINS / e));
     return b < 0 ? 0 : (b > BVB_BINS - 1 ? BVB_BINS - 1 : b);
+}
+
+// When all centroids of a node coincide (identical or concentric primitives) no bin plane separates them; a node of 1e5 such primitives
+// would become one leaf that a single thread sorts (O(n^2)) and every ray scans.  Then the node is halved by a hash bit of the primitive
+// index instead: the children share the node's box, the subtree is balanced, leaves stay small.
+__device__ __forceinline__ uint32_t bvb_hash_bit(uint32_t p, uint32_t depth) {
+    uint32_t h = p * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+    return (h >> (depth & 31u)) & 1u;
 }
 
 __global__ void bvb_init_kernel(BvbView B) {
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(BVB_THREADS) void bvb_bin_kernel(BvbView B) {
                 atomicAdd(w, 1u);
                 for (int j = 0; j < 3; j++) { atomicMax(w + 1 + j, ~bvb_ord(lo[j])); atomicMax(w + 4 + j, bvb_ord(hi[j])); }
             }
+            atomicAdd(bins + BVB_HASH_BINS + bvb_hash_bit(p, N->info & 255u) * BVB_BIN_WORDS, 1u);
         }
     }
     if (via_lds) {
@@ -185,6 +197,8 @@ __global__ void bvb_split_kernel(BvbView B) {
         }
     }
     bool split = best_axis >= 0;
+    const uint32_t h0 = bins[BVB_HASH_BINS], h1 = bins[BVB_HASH_BINS + BVB_BIN_WORDS];
+    const bool by_hash = !split && count > BVB_MAX_LEAF && depth < B.max_depth && h0 > 0 && h1 > 0; // no plane separates the centroids
     if (split && count <= BVB_MAX_LEAF && !(best < bvb_half_area(N->lo, N->hi) * (float)count)) split = false; // bvh.h:92-95
     if (depth >= B.max_depth) split = false;
     // balance guard: a node too large for the levels that are left below it splits where the counts are most even
@@ -208,6 +222,10 @@ __global__ void bvb_split_kernel(BvbView B) {
         }
         for (int j = 0; j < 3; j++) { D.llo[j] = llo[j]; D.lhi[j] = lhi[j]; D.rlo[j] = rlo[j]; D.rhi[j] = rhi[j]; }
         D.n_left = nl; D.n_right = nr; D.axis_plane = (uint32_t)best_axis | ((uint32_t)best_plane << 4);
+    }
+    if (by_hash) { // both halves keep the node's box
+        D.split = 1u; D.axis_plane = 3u; D.n_left = h0; D.n_right = h1;
+        for (int j = 0; j < 3; j++) { D.llo[j] = N->lo[j]; D.lhi[j] = N->hi[j]; D.rlo[j] = N->lo[j]; D.rhi[j] = N->hi[j]; }
     }
     B.dec[r] = D;
     for (int i = 0; i < BVB_NODE_BIN_WORDS; i++) bins[i] = 0; // the slot is clean for the next level
@@ -285,8 +303,12 @@ __global__ __launch_bounds__(BVB_THREADS) void bvb_assign_kernel(BvbView B) {
         if (N->left != 0) {
             const int axis = (int)((N->info >> 8) & 15u), plane = (int)(N->info >> 12);
             const float *b = B.boxes + 8 * (size_t)p;
-            const int bin = bvb_bin(b[axis] + b[4 + axis], bvb_unord(~N->clo[axis]), bvb_unord(N->chi[axis]));
-            const uint32_t child = N->left + (bin > plane ? 1u : 0u);
+            uint32_t child;
+            if (axis == 3) child = N->left + bvb_hash_bit(p, N->info & 255u); // the split of last resort
+            else {
+                const int bin = bvb_bin(b[axis] + b[4 + axis], bvb_unord(~N->clo[axis]), bvb_unord(N->chi[axis]));
+                child = N->left + (bin > plane ? 1u : 0u);
+            }
             B.prim_node[p] = child;
             BvbNode *C = B.nodes + child;
             if (C->count > 1) {

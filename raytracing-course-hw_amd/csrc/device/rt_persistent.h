@@ -98,7 +98,7 @@ struct PtParams {
     uint32_t front_first;             // 1: the queues serve the front of the workgroup's group list first (the host sorted it by cost, most expensive first)
     int prio;                         // experiment: 1 = walker stints run at raised wave priority (s_setprio 2), 2 = shader batches do
     unsigned long long deadline_ticks; // 100 MHz ticks a wave may spend in this launch before it gives up (error)
-    unsigned long long *counters;     // [0] closest-hit queries, [1] light queries, [2] node visits, [3] triangle tests, [10] discarded speculative hits, [12] exact closest hits, [13] exact light sums, [14] waves that gave up waiting (error)
+    unsigned long long *counters;     // [0] closest-hit queries, [1] light queries, [2] node visits, [3] triangle tests, [10] discarded speculative hits, [12] exact closest hits, [13] exact light sums, [14] waves that gave up waiting for a lost path (error), [29] waves that ran into the launch deadline (error)
     unsigned long long *debug;        // nullable: per workgroup {start time, exit time of its last wave (100 MHz ticks), paths}
     // COUNT builds, RTAMD_TRACE_PIXEL: every hit record the shader consumes for pixel trace_pixel (= y * width + x) is appended as
     // four float4 (r0..r3 of the path record: ray, hit, packed word); word 0 of trace_buf counts the entries
@@ -705,13 +705,13 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
     uint32_t n_closest = 0, n_light = 0, n_xtrace = 0, n_xlight = 0, n_discarded = 0; // per wave and launch: well below 2^32
     unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t idle_spins = 0;
-    bool gave_up = false;
+    int gave_up = 0; // 1: the launch ran into its deadline; 2: the workgroup waited in vain for a path to come back (a lost path: a bug)
     PtProf prof;
     unsigned long long t_mark = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](unsigned long long &acc) { if (COUNT) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc += t - t_mark; t_mark = t; } };
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { gave_up = true; break; } // safety net: never hang the GPU; the host reports the error
+        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { gave_up = 1; break; } // safety net: never hang the GPU; the host reports the error
         const int ns = pt_count(&sh.cnt[PT_Q_SHADE]), nt = pt_count(&sh.cnt[PT_Q_TRACE]), nl = pt_count(&sh.cnt[PT_Q_LIGHT]);
         const int nx = pt_count(&sh.cnt[PT_Q_XLIGHT]) + pt_count(&sh.cnt[PT_Q_XTRACE]);
         if (nx > 0) {
@@ -786,9 +786,9 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
         // paths are in flight in other waves' registers: wait for them
         __builtin_amdgcn_s_sleep(8);
         lap(prof.t_idle);
-        if (++idle_spins > (1u << 24)) { gave_up = true; break; } // safety net (seconds): never hang the GPU on a lost path; the host reports it
+        if (++idle_spins > (1u << 24)) { gave_up = 2; break; } // safety net (seconds): never hang the GPU on a lost path; the host reports it
     }
-    if (gave_up && lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
+    if (gave_up && lane == 0 && P.counters) atomicAdd(&P.counters[gave_up == 1 ? 29 : 14], 1ull);
     if (P.group_cost) { // every wave leaves the loop once the workgroup's pixels are done (or at the deadline)
         __syncthreads();
         for (uint32_t i = tid; i < n_local_groups; i += P8_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];

@@ -888,12 +888,12 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
     uint32_t n_closest = 0, n_light = 0, n_slow = 0, n_exact = 0, n_xlight = 0;
     unsigned long long n_nodes = 0, n_tris = 0;
     uint32_t idle_spins = 0;
-    bool gave_up = false;
+    int gave_up = 0; // 1: the launch ran into its deadline; 2: the workgroup waited in vain for a path to come back (a lost path: a bug)
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_role[5] = {0, 0, 0, 0, 0}, t_mark = t_start; // COUNT: wave time as closest-hit walker, light walker, shader, slow light sums, idle
     auto clock_role = [&](int role) { if (COUNT) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_role[role] += now - t_mark; t_mark = now; } };
     for (;;) {
-        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { gave_up = true; break; } // safety net: never hang the GPU; the host reports the error
+        if (__builtin_amdgcn_s_memrealtime() - t_start > P.deadline_ticks) { gave_up = 1; break; } // safety net: never hang the GPU; the host reports the error
         const int ns = pt_count(&sh.cnt[PT_Q_SHADE]), nt = pt_count(&sh.cnt[PT_Q_TRACE]), nl = pt_count(&sh.cnt[PT_Q_LIGHT]);
         if (pt_count(&sh.cnt[P6_Q_SLOW]) > 0) {
             // light sums with more than two hits: the reference's association over the hits the walker left in the record, one lane per
@@ -959,9 +959,9 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
         if (pt_count(&sh.cnt[PT_N_LIVE]) <= 0) break;
         __builtin_amdgcn_s_sleep(8);
         clock_role(4);
-        if (++idle_spins > (1u << 24)) { gave_up = true; break; }
+        if (++idle_spins > (1u << 24)) { gave_up = 2; break; }
     }
-    if (gave_up && lane == 0 && P.counters) atomicAdd(&P.counters[14], 1ull);
+    if (gave_up && lane == 0 && P.counters) atomicAdd(&P.counters[gave_up == 1 ? 29 : 14], 1ull);
     if (P.group_cost) { // every wave leaves the loop once the workgroup's pixels are done (or at the deadline)
         __syncthreads();
         for (uint32_t i = tid; i < n_local_groups; i += P6_THREADS) P.group_cost[sh.groups[i]] = sh.cost[i];

@@ -809,7 +809,13 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     if (const char *e = getenv("RTAMD_WF_SPLIT")) { int a = 0, b = 0; if (sscanf(e, "%d:%d", &a, &b) == 2 && a > 0 && b > 0 && a < 256 && b < 256) { P.cost_t = a; P.cost_l = b; } }
     P.prio = getenv("RTAMD_PT_PRIO") ? atoi(getenv("RTAMD_PT_PRIO")) : 0;
     P.counters = scene->d_counters;
-    P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
+    // A wave still in the launch after this long gives up (the kernel cannot hang the GPU): RTAMD_PT_TIMEOUT_S, by default ten minutes or
+    // — for long renders: 4K at thousands of samples — the time the launch would take at a twentieth of the usual rate, whichever is more.
+    {
+        const double expected_s = (double)n_work * 64.0 * (double)R.samples / 15e6;
+        const double deadline_s = getenv("RTAMD_PT_TIMEOUT_S") ? (double)env_int("RTAMD_PT_TIMEOUT_S", 600) : (expected_s > 600.0 ? expected_s : 600.0);
+        P.deadline_ticks = (unsigned long long)(deadline_s * 1e8);
+    }
     // every workgroup leaves its start and exit time (the re-deal measures the workgroups' speeds with them)
     P.debug = nullptr;
     if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
@@ -929,7 +935,13 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
     P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);
     P.cost_t = 1; P.cost_l = 1;
     P.counters = scene->d_counters;
-    P.deadline_ticks = (unsigned long long)env_int("RTAMD_PT_TIMEOUT_S", 600) * 100000000ull;
+    // A wave still in the launch after this long gives up (the kernel cannot hang the GPU): RTAMD_PT_TIMEOUT_S, by default ten minutes or
+    // — for long renders: 4K at thousands of samples — the time the launch would take at a twentieth of the usual rate, whichever is more.
+    {
+        const double expected_s = (double)n_work * 64.0 * (double)R.samples / 15e6;
+        const double deadline_s = getenv("RTAMD_PT_TIMEOUT_S") ? (double)env_int("RTAMD_PT_TIMEOUT_S", 600) : (expected_s > 600.0 ? expected_s : 600.0);
+        P.deadline_ticks = (unsigned long long)(deadline_s * 1e8);
+    }
     // every workgroup leaves its start and exit time (the re-deal measures the workgroups' speeds with them)
     if (!scene->d_pt_debug) HIP_CHECK(hipMalloc((void **)&scene->d_pt_debug, (size_t)PT_DEBUG_BLOCKS * 3 * sizeof(unsigned long long)));
     if (n_blocks_max <= PT_DEBUG_BLOCKS) P.debug = scene->d_pt_debug;
@@ -1186,9 +1198,11 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 }
             }
         }
+        if (use_persistent6 && h_cnt[29]) return fail(RT_ERR_LIMIT, "rt_render: the persistent hw6 kernel ran into its launch deadline (" + std::to_string(h_cnt[29]) + " waves; RTAMD_PT_TIMEOUT_S raises it); the frame is incomplete");
         if (use_persistent6 && h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent hw6 kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");
         scene->pipeline = (use_persistent || use_persistent6) ? RT_PIPELINE_PERSISTENT : (use_wavefront && blocks ? RT_PIPELINE_ROUNDS : RT_PIPELINE_SINGLE);
         if (use_persistent) {
+            if (h_cnt[29]) return fail(RT_ERR_LIMIT, "rt_render: the persistent kernel ran into its launch deadline (" + std::to_string(h_cnt[29]) + " waves; RTAMD_PT_TIMEOUT_S raises it); the frame is incomplete");
             if (h_cnt[14]) return fail(RT_ERR_HIP, "rt_render: the persistent kernel lost a path (" + std::to_string(h_cnt[14]) + " waves gave up waiting); the frame is incomplete");
             h_cnt[0] -= h_cnt[10] < h_cnt[0] ? h_cnt[10] : h_cnt[0]; // speculative closest-hit queries that the clamp step discarded are not part of the algorithm
             if (getenv("RTAMD_DEBUG_COUNTERS") && scene->d_pt_debug && scene->pt_blocks <= PT_DEBUG_BLOCKS) {

@@ -358,8 +358,9 @@ RT_DEV F3 load_texel(const SceneView &S, const GpuImage &im, int ix, int iy, boo
     const float k = (float)(1. / 255);
     return f3(k * (1.f * (float)r), k * (1.f * (float)g), k * (1.f * (float)b));
 }
-RT_DEV F3 sample_texture(const SceneView &S, int slot, float tx, float ty, bool srgb) {
-    GpuImage im = S.images[slot];
+RT_DEV F3 sample_texture(const SceneView &S, GpuImage im, float tx, float ty, bool srgb); // with the image's descriptor already loaded
+RT_DEV F3 sample_texture(const SceneView &S, int slot, float tx, float ty, bool srgb) { return sample_texture(S, S.images[slot], tx, ty, srgb); }
+RT_DEV F3 sample_texture(const SceneView &S, GpuImage im, float tx, float ty, bool srgb) {
     tx -= floorf(tx);
     ty -= floorf(ty);
     tx *= im.width;

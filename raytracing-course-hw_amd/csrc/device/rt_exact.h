@@ -134,7 +134,18 @@ RT_DEV float pt_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 //     a_j + b_k >= c1 t + c2 (1/|d_j| + 1/|d_k|),   c1 = 2^-19,  c2 = 2^-20 max|coordinate|   (4x the bound)
 // is sufficient, and t + b_k >= c1 t keeps the exit in front of the origin.  Boxes only grow towards the root, which only
 // increases a_j and b_k.  A flat box (a_j = b_j = 0 on its axis) passes as long as the other axes have room.
+// The common case of both tests below, for a dozen instructions: the hit point lies deep inside the box — at least c2 + 2^-19 t max|d_k| from every
+// face.  Then every a_j, b_k below is >= (m - c2) / max|d_k| >= 2^-19 t, so a_j + b_k >= 2 need, the exit lies beyond t, and the window of
+// pt_hit_stands (need - min a) is <= 0.  Flat boxes (axis-aligned triangles) and hits near a box face take the full test.  NaN: false.
+RT_DEV bool pt_deep_inside(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
+    const float m = fminf(fminf(fminf(P.x - lo.x, hi.x - P.x), fminf(P.y - lo.y, hi.y - P.y)), fminf(P.z - lo.z, hi.z - P.z));
+    const float dmax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    return m - c2 >= 1.9073486328125e-06f * t * dmax;
+}
+
+template <bool PRETEST = true>
 RT_DEV bool pt_box_robust(F3 lo, F3 hi, F3 P, F3 d, float t, float c2) {
+    if (PRETEST && pt_deep_inside(lo, hi, P, d, t, c2)) return true;
     const float ix = pt_rcp(fmaxf(fabsf(d.x), 1e-30f)), iy = pt_rcp(fmaxf(fabsf(d.y), 1e-30f)), iz = pt_rcp(fmaxf(fabsf(d.z), 1e-30f));
     const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
     const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
@@ -182,6 +193,7 @@ RT_DEV float pt_look_behind_abs(F3 d, float c2x) {
 // does not reach past what the walkers looked at (a hit reported well in front of its own box).
 RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2, float c2x, float cull_k) {
     const F3 P = o + t * d;
+    if (pt_deep_inside(lo, hi, P, d, t, c2)) return gap > 0.f && gap > 4.8e-7f * (t + gap); // box and window conditions hold (window <= 0): only the tie rule is left
     const float ix = pt_rcp(fmaxf(fabsf(d.x), 1e-30f)), iy = pt_rcp(fmaxf(fabsf(d.y), 1e-30f)), iz = pt_rcp(fmaxf(fabsf(d.z), 1e-30f));
     const float inx = d.x > 0 ? P.x - lo.x : hi.x - P.x, outx = d.x > 0 ? hi.x - P.x : P.x - lo.x;
     const float iny = d.y > 0 ? P.y - lo.y : hi.y - P.y, outy = d.y > 0 ? hi.y - P.y : P.y - lo.y;
@@ -205,7 +217,7 @@ RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d,
     float t, u, v; bool inside;
     if (!tri_test(T, x, d, t, u, v, inside)) return 0.f;
     const float4 *q = reinterpret_cast<const float4 *>(L) + 3;
-    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    float4 q1 = q[1], q2 = q[2], q3 = q[3];
     float point_prob = q1.z;
     F3 n3 = f3(q1.w, q2.x, q2.y), dn1 = f3(q2.z, q2.w, q3.x), dn2 = f3(q3.y, q3.z, q3.w);
     F3 sn = n3 + u * dn1 + v * dn2;           // primitives.cpp:110
@@ -213,11 +225,9 @@ RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d,
     if (inside) sn = neg(sn);                  // :118-119
     if (S.hw7) { F3 n = f3(T.nx, T.ny, T.nz); sn = normalize(inside ? neg(n) : n); }
     F3 y = x + t * d;                          // distributions.h:144
-    if (S.exact_boxes) {
-        const F3 a = f3(T.ax, T.ay, T.az), pb = a + f3(q0.x, q0.y, q0.z), pc = a + f3(q0.w, q1.x, q1.y);
-        const F3 lo = f3(fminf(a.x, fminf(pb.x, pc.x)), fminf(a.y, fminf(pb.y, pc.y)), fminf(a.z, fminf(pb.z, pc.z)));
-        const F3 hi = f3(fmaxf(a.x, fmaxf(pb.x, pc.x)), fmaxf(a.y, fmaxf(pb.y, pc.y)), fmaxf(a.z, fmaxf(pb.z, pc.z)));
-        robust = pt_box_robust(lo, hi, y, d, t, S.box_c2);
+    if (S.exact_boxes == 1u) {
+        const float4 blo = q[4], bhi = q[5];   // the light's own box (LightRec::box_lo / box_hi)
+        robust = pt_box_robust(f3(blo.x, blo.y, blo.z), f3(bhi.x, bhi.y, bhi.z), y, d, t, S.box_c2);
     }
     return point_prob * len2(x - y) / fabsf(dot(d, sn)); // :68-70 (pdfOne, shading normal in hw8)
 }

@@ -17,30 +17,37 @@ struct Shaded {
 };
 
 // The hit triangle's geometric normal, flipped towards the ray's side (primitives.cpp:21-24,123).
-RT_DEV F3 geom_normal(const SceneView &S, const HitRec &h) {
-    const float4 *qi = reinterpret_cast<const float4 *>(S.tri_isect + h.idx);
-    float4 i0 = qi[0], i1 = qi[1];
-    F3 n = f3(i0.w, i1.x, i1.y);
-    return normalize(h.inside ? neg(n) : n);
+RT_DEV F3 geom_normal(F3 n, bool inside) { return normalize(inside ? neg(n) : n); }
+RT_DEV F3 load_tri_normal(const SceneView &S, uint32_t fig) { // n = b x c of TriIsect (words 3..5)
+    const float4 *qi = reinterpret_cast<const float4 *>(S.tri_isect + fig);
+    const float4 i0 = qi[0], i1 = qi[1];
+    return f3(i0.w, i1.x, i1.y);
 }
+RT_DEV F3 geom_normal(const SceneView &S, const HitRec &h) { return geom_normal(load_tri_normal(S, (uint32_t)h.idx), h.inside); }
 
 // Everything Scene::getColor does between the intersection and the direction sampling
 // (scene.cpp:99-149): interpolate attributes, fetch the material, sample the textures, normal map.
-RT_DEV void shade_fetch_attr(const SceneView &S, const HitRec &h, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
+// TriShade quads 4..6 (dt2.yz uv3.xy | duv1.xy duv2.xy | tanw material orig pad) of the hit figure: what shade_fetch_attr needs first.  A caller
+// that knows the figure early (the persistent shader: from the hit word, before its gate) loads them along with everything else whose
+// address it knows, so that one memory latency covers them all.
+struct TriShadeHead { float4 s4, s5, s6; };
+RT_DEV TriShadeHead load_shade_head(const SceneView &S, uint32_t fig) {
+    const float4 *q = reinterpret_cast<const float4 *>(S.tri_shade + fig);
+    TriShadeHead H; H.s4 = q[4]; H.s5 = q[5]; H.s6 = q[6];
+    return H;
+}
+
+RT_DEV void shade_fetch_attr(const SceneView &S, const HitRec &h, const TriShadeHead &H, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
     // TriShade: s0 = n3.xyz dn1.x | s1 = dn1.yz dn2.xy | s2 = dn2.z t3.xyz | s3 = dt1.xyz dt2.x
     //           s4 = dt2.yz uv3.xy | s5 = duv1.xy duv2.xy | s6 = tanw material orig pad
     // Read in the order of use — texture coordinates and material first, normal and tangent bases after the texture taps — so that the
     // bases do not sit in registers while the taps run (the interpolations themselves are the reference's, primitives.cpp:110-119).
     const float4 *q = reinterpret_cast<const float4 *>(S.tri_shade + h.idx);
     const float u = h.u, v = h.v;
-    float tu, tv, tanw; uint32_t mat;
-    {
-        const float4 s4 = q[4], s5 = q[5], s6 = q[6];
-        tu = s4.z + u * s5.x + v * s5.z;                  // :111-114
-        tv = s4.w + u * s5.y + v * s5.w;
-        tanw = s6.x;
-        mat = __float_as_uint(s6.y);
-    }
+    const float tu = H.s4.z + u * H.s5.x + v * H.s5.z;    // :111-114
+    const float tv = H.s4.w + u * H.s5.y + v * H.s5.w;
+    const float tanw = H.s6.x;
+    const uint32_t mat = __float_as_uint(H.s6.y);
     const float4 *qm = reinterpret_cast<const float4 *>(S.materials + mat);
     float4 m0 = qm[0], m1 = qm[1], m2 = qm[2];
     base_color = f3(m0.x, m0.y, m0.z); base_metallic = m0.w;
@@ -50,10 +57,13 @@ RT_DEV void shade_fetch_attr(const SceneView &S, const HitRec &h, Shaded &sh, F3
     sh.color = f3(1.f, 1.f, 1.f);
     sh.emission = f3(m1.x, m1.y, m1.z);
     if (!hw7) {
-        if (tex_color >= 0) sh.color = sample_texture(S, tex_color, tu, tv, true);      // scene.cpp:107-115
-        if (tex_emis >= 0) sh.emission = sh.emission * sample_texture(S, tex_emis, tu, tv, true); // :117-125
-        if (tex_mr >= 0) mr = sample_texture(S, tex_mr, tu, tv, false);                 // :127-135
-        if (tex_nrm >= 0) ns = sample_texture(S, tex_nrm, tu, tv, false);               // :137-145
+        // the four image descriptors go out together (slot 0 stands in for an absent texture: the load is then unused)
+        const GpuImage im_c = S.images[tex_color >= 0 ? tex_color : 0], im_e = S.images[tex_emis >= 0 ? tex_emis : 0];
+        const GpuImage im_m = S.images[tex_mr >= 0 ? tex_mr : 0], im_n = S.images[tex_nrm >= 0 ? tex_nrm : 0];
+        if (tex_color >= 0) sh.color = sample_texture(S, im_c, tu, tv, true);           // scene.cpp:107-115
+        if (tex_emis >= 0) sh.emission = sh.emission * sample_texture(S, im_e, tu, tv, true);     // :117-125
+        if (tex_mr >= 0) mr = sample_texture(S, im_m, tu, tv, false);                   // :127-135
+        if (tex_nrm >= 0) ns = sample_texture(S, im_n, tu, tv, false);                  // :137-145
     }
     F3 sn;
     {
@@ -86,7 +96,7 @@ RT_DEV void shade_fetch_attr(const SceneView &S, const HitRec &h, Shaded &sh, F3
 
 RT_DEV void shade_fetch(const SceneView &S, const HitRec &h, F3 &ng, Shaded &sh, F3 &base_color, float &base_metallic, bool hw7) {
     ng = geom_normal(S, h);
-    shade_fetch_attr(S, h, sh, base_color, base_metallic, hw7);
+    shade_fetch_attr(S, h, load_shade_head(S, (uint32_t)h.idx), sh, base_color, base_metallic, hw7);
 }
 
 // Only the emission of a hit (scene.cpp:117-125) — all the deepest level of a path can contribute when the

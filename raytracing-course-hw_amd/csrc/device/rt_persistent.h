@@ -463,28 +463,32 @@ template <int FEAT>
 RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &W, const uint32_t slot, const PtPark pk, bool &discarded) {
     float4 *r = wf_rec(W, slot);
     uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
-    {   // the exactness gate (pt_shade_item): a hit that does not stand as the reference's answer goes to the exact walk first, untouched
-        const float4 q0 = r[0], q1 = r[1];
-        if (S.exact_boxes) {
-            const float4 q2 = r[2];
-            const uint32_t hit = __float_as_uint(q2.w);
-            if (hit != WF_MISS && !(packed & WF_VERIFIED_BIT)) {
-                const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)(hit & WF_INDEX_MASK);
-                const float4 lo = bx[0], hi = bx[1];
-                if (!pt_hit_stands(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z), f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), q2.x, pt_gap_floor(hit, q2.x), S.box_c2, S.box_c2x, S.cull_k))
-                    return PT_SHADE_EXACT;
-            }
-        }
-        pk.put(PK_D, q0.w); pk.put(PK_D + 1, q1.x); pk.put(PK_D + 2, q1.y);
-        pk.putu(PK_RNG, __float_as_uint(q1.z)); pk.put(PK_RNG + 1, q1.w);
-    }
     int depth = (int)(packed & 15u);
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+    const uint32_t hit = __float_as_uint(q2.w);
+    // Everything whose address is known once the record is in goes out together — the figure's box (the gate), its plane normal, the head of
+    // its TriShade record (texture coordinates, material), the pending bounce's entry — so that ONE memory latency covers what would otherwise
+    // be four dependent round trips (gate -> entry -> normal -> attributes).  Lanes without a hit read figure 0, lanes without a pending
+    // bounce read their level's entry anyway: the values are simply not used.
+    const uint32_t fig = hit != WF_MISS ? (hit & WF_INDEX_MASK) : 0u;
+    float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
+    if (S.exact_boxes) { const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)fig; blo = bx[0]; bhi = bx[1]; }
+    const F3 tri_n = load_tri_normal(S, fig);
+    const TriShadeHead head = load_shade_head(S, fig);
+    float4 pe0, pe1;
+    { const float4 *e = wf_entry(W, slot, depth); pe0 = e[0]; pe1 = e[1]; }
+    // the exactness gate (pt_shade_item): a hit that does not stand as the reference's answer goes to the exact walk first, untouched
+    if (S.exact_boxes == 1u && hit != WF_MISS && !(packed & WF_VERIFIED_BIT) &&
+        !pt_hit_stands(f3(blo.x, blo.y, blo.z), f3(bhi.x, bhi.y, bhi.z), f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), q2.x, pt_gap_floor(hit, q2.x), S.box_c2, S.box_c2x, S.cull_k))
+        return PT_SHADE_EXACT;
+    pk.put(PK_D, q0.w); pk.put(PK_D + 1, q1.x); pk.put(PK_D + 2, q1.y);
+    pk.putu(PK_RNG, __float_as_uint(q1.z)); pk.put(PK_RNG + 1, q1.w);
     bool ended = false;
     if (packed & WF_PENDING_BIT) {
         // The bounce at `depth` sampled the ray that was just traced; its pdf is complete now (Mix::pdf, distributions.h:268-278).
         float4 *e = wf_entry(W, slot, depth);
-        const float4 e0 = e[0], e1 = e[1];
-        const float pdf = e0.w / S.n_components_f;                             // :278
+        const float4 e0 = pe0, e1 = pe1;
+        const float pdf = e0.w / S.n_components_f;                                  // :278
         const float k = (float)(1. / (double)pdf * fabs((double)e1.w));             // scene.cpp:159
         F3 mult = k * f3(e1.x, e1.y, e1.z);
         const bool clamp = mult.x > 6.f || mult.y > 6.f || mult.z > 6.f || mult.x != mult.x || mult.y != mult.y || mult.z != mult.z;
@@ -509,8 +513,6 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
         }
     }
     if (!ended) {
-        const float4 q2 = r[2];
-        const uint32_t hit = __float_as_uint(q2.w);
         HitRec h;
         h.idx = (int)(hit & WF_INDEX_MASK); h.inside = (hit & WF_INSIDE_BIT) != 0; h.t = q2.x; h.u = q2.y; h.v = q2.z;
         if (hit == WF_MISS) { ended = true; pk.end(miss_color<(FEAT & WF_FEAT_ENV) != 0>(S, pk.get3(PK_D)), depth); }
@@ -529,8 +531,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
             const bool hw7 = (FEAT & WF_FEAT_HW7) && S.hw7;
             float4 *e = wf_entry(W, slot, depth);
             {   // the next ray's origin goes to the path's record at once (its final place): x + eps * geomNorma, scene.cpp:104
-                const F3 ng = geom_normal(S, h);
-                const float4 q0 = r[0];
+                const F3 ng = geom_normal(tri_n, h.inside);
                 const F3 x = f3(q0.x, q0.y, q0.z) + h.t * pk.get3(PK_D);
                 const F3 xo = x + 9.99999974737875163555e-05f * ng;
                 r[0] = make_float4(xo.x, xo.y, xo.z, 0.f);                           // the next ray doubles as the light query
@@ -540,7 +541,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
                 // hit attributes, material, textures (scene.cpp:99-149).  The emission goes to the level's entry at once; colour and
                 // metallic shrink to the products the BRDF uses and wait in the park.
                 F3 base_color; float base_metallic; Shaded sh;
-                shade_fetch_attr(S, h, sh, base_color, base_metallic, hw7);
+                shade_fetch_attr(S, h, head, sh, base_color, base_metallic, hw7);
                 e[0] = make_float4(sh.emission.x, sh.emission.y, sh.emission.z, 0.f);
                 pk.put3(PK_BC, base_color * sh.color);
                 pk.put(PK_BC + 3, sh.metallic * base_metallic);

@@ -38,6 +38,9 @@ namespace dev {
 #define P6_COST_TRACE_STEP 1u        // what a sub-tile costs its workgroup, in closest-hit node steps (the measure of the re-deal, as PT_COST_*)
 #define P6_COST_LIGHT_STEP 2u
 #define P6_COST_SHADE 10u
+#ifndef P6_LIGHT_PRETEST
+#define P6_LIGHT_PRETEST false   // the deep-inside shortcut of pt_box_robust in the light walker: its few extra live values are exactly what tips this kernel (at 96 VGPRs) into spilling
+#endif
 #define P6_MERGE_HITS 13             // p6_merge_hits works in the lane's own 28-word column: 13 terms + 14 index / depth words
 #define P6_Q_SLOW 3                  // light sums with more than two hits: the complete per-lane light_pdf_sum6_fast
 #define P6_REC 56u                   // float4 per path record: 8 + 5 per frame x RT6_MAX_DEPTH + 8 for the hits of a light sum
@@ -57,14 +60,16 @@ namespace dev {
 #define P6_PARKED 8
 #define P6_EXACT 16                  // the hit does not stand as the reference's answer: exact walk first, nothing of the path was touched
 
+typedef __attribute__((address_space(3))) uint32_t *P6Lds; // an LDS pointer that stays one: 32 bits, not a 64-bit generic pointer in two VGPRs
+typedef __attribute__((address_space(3))) float *P6LdsF;
 struct P6Slice { // a strided view of the wave's LDS stack area: indexable like an array
-    uint32_t *p;
-    RT_DEV uint32_t &operator[](int i) const { return p[P6_XBATCH * i]; }
+    P6Lds p;
+    RT_DEV __attribute__((address_space(3))) uint32_t &operator[](int i) const { return p[P6_XBATCH * i]; }
     RT_DEV P6Slice at(int first_word) const { P6Slice s; s.p = p + P6_XBATCH * first_word; return s; }
 };
 struct P6SliceF { // the same words read as floats
-    uint32_t *p;
-    RT_DEV float &operator[](int i) const { return reinterpret_cast<float *>(p)[P6_XBATCH * i]; }
+    P6Lds p;
+    RT_DEV __attribute__((address_space(3))) float &operator[](int i) const { return ((P6LdsF)p)[P6_XBATCH * i]; }
 };
 
 struct P6Shared {
@@ -494,7 +499,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                             const F3 pb = T.a + T.b, pc = T.a + T.c;
                             const F3 blo = f3(fminf(T.a.x, fminf(pb.x, pc.x)), fminf(T.a.y, fminf(pb.y, pc.y)), fminf(T.a.z, fminf(pb.z, pc.z)));
                             const F3 bhi = f3(fmaxf(T.a.x, fmaxf(pb.x, pc.x)), fmaxf(T.a.y, fmaxf(pb.y, pc.y)), fmaxf(T.a.z, fmaxf(pb.z, pc.z)));
-                            if (!pt_box_robust(blo, bhi, y, d, t, S.box_c2)) fragile = true;
+                            if (!pt_box_robust<P6_LIGHT_PRETEST>(blo, bhi, y, d, t, S.box_c2)) fragile = true;
                         }
                         if (k == 0) { term0 = term; idx0 = T.ref_index; }
                         else if (k == 1) { term1 = term; idx1 = T.ref_index; }
@@ -765,10 +770,11 @@ RT_DEV float ref_light_pdf_sum6(const SceneView6 &S, F3 x, F3 d, A stack) {
 // Light sums the walker could not finish: a hit at a box boundary (the reference's own box tests decide, along the paths to the hits),
 // or more hits than p6_merge_hits takes (the plain reference-order walk).
 template <class SH>
-RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &wv, uint32_t *area, uint32_t got, bool mine, uint32_t &n_xlight) {
+RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &wv, P6Lds area, uint32_t got, bool mine, uint32_t &n_xlight) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t base = 0; base < 64u; base += P6_XBATCH) { // the wave's lanes take turns at the slices, eight at a time
         if (!__ballot(mine && lane >= base && lane < base + P6_XBATCH)) continue;
+        bool boundary = false;
         if (mine && lane >= base && lane < base + P6_XBATCH) {
             P6Slice sl; sl.p = area + (lane - base);
             float4 *r = p6_rec(W, pt_slot(sh, got));
@@ -777,6 +783,7 @@ RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &
             const float4 q0 = r[0], q1 = r[1], q4 = r[4];
             const F3 lx = f3(q4.x, q4.y, q4.z), ld = f3(q0.w, q1.x, q1.y);
             float v;
+            boundary = (kw >> 31) != 0u;
             if (kw >> 31) { // a hit at a box boundary
                 if (k > RT6_MAX_LIGHT_HITS) v = ref_light_pdf_sum6(S, lx, ld, sl);
                 else {
@@ -787,17 +794,17 @@ RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &
                     for (int i = 0; i < k; i++) { const float2 e = h[i]; hit_idx[i] = __float_as_uint(e.x); hit_term[i] = e.y; }
                     v = ref_light_pdf_sum6_along(S, lx, ld, hit_idx, hit_term, k, f_node, f_lo, f_hi, f_val);
                 }
-                n_xlight++;
             } else if (k <= RT6_MAX_LIGHT_HITS) v = p6_merge_hits_in(S, reinterpret_cast<const float2 *>(r + 48), k, sl.at(0), sl.at(RT6_MAX_LIGHT_HITS)); // more hits than a column takes
             else v = light_pdf_sum6(S, lx, ld, sl);       // more hits than the record holds: the plain reference-order walk
             reinterpret_cast<float *>(r + 4)[3] = v;
         }
+        n_xlight += (uint32_t)__popcll(__ballot(boundary)); // wave-uniform
     }
 }
 
 // Closest hits that do not stand as the reference's answer (~1e-4 of them): the reference's own walk.
 template <class SH>
-RT_DEV void p6_exact_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &wv, uint32_t *area, uint32_t &n_exact) {
+RT_DEV void p6_exact_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &wv, P6Lds area, uint32_t &n_exact) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t got = pt_pop(sh.need[P6_Q_XTRACE], &sh.cnt[P6_Q_XTRACE], wv.nw, wv.cur[P6_Q_XTRACE], lane < P6_XBATCH);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -908,7 +915,7 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
                 if ((kw >> 31) || kw > (uint32_t)P6_MERGE_HITS) batch = true;
                 else reinterpret_cast<float *>(r + 4)[3] = p6_merge_hits(S, reinterpret_cast<const float2 *>(r + 48), (int)kw, stack);
             }
-            if (__ballot(batch)) p6_slow_batch(S, W, sh, wv, &stack[0][0], got, batch, n_xlight); // the merges are done: their columns are free
+            if (__ballot(batch)) p6_slow_batch(S, W, sh, wv, (P6Lds)&stack[0][0], got, batch, n_xlight); // the merges are done: their columns are free
             n_slow += __popcll(__ballot(got != PT_NONE));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
             continue;
         }
         if (pt_count(&sh.cnt[P6_Q_XTRACE]) > 0) {
-            p6_exact_batch(S, W, sh, wv, &stack[0][0], n_exact);
+            p6_exact_batch(S, W, sh, wv, (P6Lds)&stack[0][0], n_exact);
             idle_spins = 0;
             clock_role(3);
             continue;
@@ -972,7 +979,7 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
         if (n_slow) atomicAdd(&P.counters[13], (unsigned long long)n_slow);
         if (n_exact) atomicAdd(&P.counters[12], (unsigned long long)n_exact);
     }
-    if (n_xlight && P.counters) atomicAdd(&P.counters[11], (unsigned long long)n_xlight); // per lane: each counted its own queries
+    if (lane == 0 && n_xlight && P.counters) atomicAdd(&P.counters[11], (unsigned long long)n_xlight);
     if (COUNT && P.counters) {
         atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris);
         if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&P.counters[16 + i], t_role[i]);

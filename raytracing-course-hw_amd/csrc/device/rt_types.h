@@ -51,8 +51,10 @@ struct LightRec {
     float b[3], c[3];              // for TriangleLight::sample: point = a + u*b + v*c
     float point_prob;              // 1 / area
     float n3[3], dn1[3], dn2[3];   // shading-normal interpolation (pdfOne uses the shading normal in hw8)
+    float box_lo[3], pad0;         // the light's own box: min / max over a, a + b, a + c in float (what the robustness test of rt_exact.h compares a hit
+    float box_hi[3], pad1;         // point with; formed on the host instead of 24 instructions per light hit)
 };
-static_assert(sizeof(LightRec) == 48 + 64, "LightRec must be 112 bytes");
+static_assert(sizeof(LightRec) == 48 + 64 + 32, "LightRec must be 144 bytes");
 
 // Node of the reference's own tree with its UNPADDED box (hw8/src/include/bvh.h:9-16), for the reference-exact walks of
 // rt_persistent.h: left == 0 marks a leaf holding the figures (lights) [first, last) of the reference order.

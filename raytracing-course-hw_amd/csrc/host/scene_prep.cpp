@@ -410,6 +410,14 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
         float nl2 = L.isect.nx * L.isect.nx + L.isect.ny * L.isect.ny + L.isect.nz * L.isect.nz;
         float nl = (float)std::sqrt((double)nl2);
         L.point_prob = (float)(1.0 / (0.5 * (double)nl)); // distributions.h:78
+        { // the box the kernel used to form per hit: a, a + b, a + c in float (not the original vertices)
+            const float av[3] = {L.isect.ax, L.isect.ay, L.isect.az};
+            for (int k = 0; k < 3; k++) {
+                const float pb = av[k] + L.b[k], pc = av[k] + L.c[k];
+                L.box_lo[k] = std::fmin(av[k], std::fmin(pb, pc));
+                L.box_hi[k] = std::fmax(av[k], std::fmax(pb, pc));
+            }
+        }
         if (d.normals) {
             const float *q = d.normals + 9 * (size_t)src;
             for (int k = 0; k < 3; k++) { L.n3[k] = q[6 + k]; L.dn1[k] = q[k] - q[6 + k]; L.dn2[k] = q[3 + k] - q[6 + k]; }

@@ -380,9 +380,11 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
         V.ref_nodes = keep(upload(P.ref_nodes, bytes));
         V.ref_light_nodes = keep(upload(P.ref_light_nodes, bytes));
         V.box_c2 = P.box_c2; V.box_c2x = 1.25f * P.box_c2;
+        if (const char *e = getenv("RTAMD_C2X_SCALE")) V.box_c2x *= (float)atof(e); // experiment: the walkers' absolute look-behind (the gate's `seen` follows)
         // how far behind the best hit the walkers still look, relative to t (rt_exact.h)
         V.cull_k = getenv("RTAMD_CULL_K") ? (float)atof(getenv("RTAMD_CULL_K")) : 0.0078125f;
         V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || fast_build) ? 0u : 1u; // RT_BUILD_DEVICE_BVH: there is no reference tree to be exact about
+        if (getenv("RTAMD_DIAG_LOOKBEHIND_ONLY")) V.exact_boxes = 2u; // diagnostic (timing only, pixels NOT exact): the walkers look behind as with the gate, every hit stands
         V.lights = keep(upload(P.lights, bytes));
         V.materials = keep(upload(P.materials, bytes));
         V.images = keep(upload(P.images, bytes));
@@ -1263,7 +1265,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             stats->launches = launches;
             stats->pipeline = (uint32_t)scene->pipeline;
             stats->reference_exact = p->integrator == RT_INTEGRATOR_HW5 ? 1u : use_persistent6 ? (scene->view6.exact_boxes ? 1u : 0u)
-                                     : ((scene->flavor == RT_INTEGRATOR_HW8 && (use_persistent || (use_wavefront && blocks)) && V8.exact_boxes) ? 1u : 0u);
+                                     : ((scene->flavor == RT_INTEGRATOR_HW8 && (use_persistent || (use_wavefront && blocks)) && V8.exact_boxes == 1u) ? 1u : 0u);
             if (use_persistent || use_persistent6) {
                 double sum = 0;
                 for (uint32_t pp = 0; time_trace && pp < scene->pt_launches; pp++) { float e = 0; HIP_CHECK(hipEventElapsedTime(&e, scene->ev_pool[2 * pp], scene->ev_pool[2 * pp + 1])); sum += e; }

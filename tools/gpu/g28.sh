@@ -1,0 +1,8 @@
+set -o pipefail
+mkdir -p gpurun_out
+: > gpurun_out/r3_probe14.log
+for e in "X=1" "RTAMD_CULL_K=0.001953125" "RTAMD_CULL_K=0.000244" "RTAMD_CULL_K=0.00001" "RTAMD_NO_EXACT_BOXES=1"; do
+  echo "== $e" >> gpurun_out/r3_probe14.log
+  env $e timeout -k 10 200 python tools/tuning/pt_probe.py --spp 256 --reps 2 "" >> gpurun_out/r3_probe14.log 2>&1 || exit $?
+done
+grep "==\|Msamples" gpurun_out/r3_probe14.log | sed 's/, pipeline 2//'

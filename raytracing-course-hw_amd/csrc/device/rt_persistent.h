@@ -502,7 +502,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
             bool survives = true;
             if (R.rr_depth > 0 && depth + 1 >= R.rr_depth) { // Russian roulette (throughput mode only), see wf_shade_item
                 Rng rng = pk.rng(packed);
-                const float q = fminf(1.f, fmaxf(0.05f, fmaxf(mult.x, fmaxf(mult.y, mult.z))));
+                const float q = wf_roulette_q(W, slot, depth, mult);
                 survives = rng_u01(rng) < q;
                 mult = (1.f / q) * mult;
                 pk.keep(rng, packed);

@@ -119,6 +119,19 @@ RT_DEV void wf_camera_ray(const SceneView &S, const RenderView &R, Rng &rng, int
     d = normalize(cx * f3(S.cam_right) - cy * f3(S.cam_up) + f3(S.cam_fwd));
 }
 
+// Russian roulette (throughput mode, RT_FLAG_RUSSIAN_ROULETTE): survival probability of the bounce at `depth` whose throughput factor is `mult`.
+// q = the largest component of the path's ACCUMULATED throughput up to and including this bounce (the factors of the earlier levels are in
+// their entries; survivors carry 1 / q, so the accumulated throughput of a path that played before hovers around 1), between 0.25 and 1.  Per-bounce
+// throughput alone (round 2: q = max component of `mult`, floor 0.05) kills bright paths as readily as dim ones: −28 % queries for 2.7x the variance.
+RT_DEV float wf_roulette_q(const WfView &W, uint32_t slot, int depth, F3 mult) {
+    F3 beta = mult;
+    for (int b = 0; b < depth; b++) {
+        const float4 e1 = wf_entry(W, slot, b)[1];
+        beta = beta * f3(e1.x, e1.y, e1.z);
+    }
+    return fminf(1.f, fmaxf(0.25f, fmaxf(beta.x, fmaxf(beta.y, beta.z))));
+}
+
 // End of one camera sample: fold e + m*(inner) backwards (scene.cpp:164), add to the pixel sum
 // (scene.cpp:174), then either start the next sample (returns WF_NEXT_TRACE: the slot holds a new camera ray that wants
 // tracing; WF_PARKED instead when that sample belongs to the next phase of the frame, R.sample_stop) or write the finished
@@ -674,7 +687,7 @@ RT_DEV int wf_shade_item(const SceneView &S, const RenderView &R, const WfView &
             if (R.rr_depth > 0 && depth + 1 >= R.rr_depth) {
                 // Russian roulette (throughput mode only): the bounce continues with probability q and carries mult / q, else the
                 // path returns its emission as if the inner call were 0 (the traced hit is dropped like a clamped one).
-                const float q = fminf(1.f, fmaxf(0.05f, fmaxf(mult.x, fmaxf(mult.y, mult.z))));
+                const float q = wf_roulette_q(W, slot, depth, mult);
                 survives = rng_u01(rng) < q;
                 mult = (1.f / q) * mult;
             }

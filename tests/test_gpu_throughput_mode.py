@@ -93,7 +93,8 @@ def test_russian_roulette_and_per_sample_seeds(rt, sphere_scene):
     """SURVEY 8(f)3, the non-replay estimator options of throughput mode.  RT_FLAG_SAMPLE_SEEDS: every camera sample has its own
     engine seeded from (pixel, sample index), so the image does not depend on how the samples are dealt to streams (up to the
     order of the float additions).  RT_FLAG_RUSSIAN_ROULETTE: paths die early with probability 1 - q and survivors are weighted
-    1 / q — fewer queries, the same expectation: against a 2048-spp replay render the bias stays within 4 standard errors."""
+    1 / q — fewer queries, the same expectation: against a 2048-spp replay render the bias stays within 4 standard errors, and variance x
+    queries does not get worse."""
     scene = rt.Scene(sphere_scene)
     w, h = 96, 64
     conv, _, _ = scene.render(w, h, 2048, want_rgb8=False)
@@ -118,3 +119,8 @@ def test_russian_roulette_and_per_sample_seeds(rt, sphere_scene):
     assert 0.75 < rmse_s / rmse_t < 1.33 and abs(bias_s) < 4 * se_s + 1e-6
     assert 0.75 < rmse_r / rmse_t < 2.0 and abs(bias_r) < 4 * se_r + 1e-6
     assert st_rr.closest_hit_queries < st_thr.closest_hit_queries
+    # and it has to pay: variance x work (closest-hit queries) must not exceed the figure without roulette (q follows the path's accumulated
+    # throughput, floor 0.25; round 2's per-bounce q lost a factor of two here)
+    eff = (rmse_r ** 2 * st_rr.closest_hit_queries) / (rmse_s ** 2 * st_thr.closest_hit_queries)
+    print(f"roulette: variance x queries relative to no roulette = {eff:.3f}")
+    assert eff <= 1.05

@@ -162,8 +162,10 @@ typedef struct rt_scene_desc {
  * RT_FLAG_SAMPLE_SEEDS     every camera sample draws from its own engine, seeded with a hash of (pixel, sample index), instead of
  *                          continuing its stream's engine: samples of a pixel are then independent of how they are dealt to streams;
  * RT_FLAG_RUSSIAN_ROULETTE from the third bounce on a path survives a bounce with probability q = clamp(max component of the
- *                          bounce's throughput factor, 0.05, 1) and its factor is divided by q (the reference ends paths by depth
- *                          and its clamp hack only, hw8/src/scene.cpp:85-87,161-163; both stay in force). */
+ *                          path's accumulated throughput up to and including this bounce, 0.25, 1) and the bounce's factor is divided
+ *                          by q (the reference ends paths by depth and its clamp hack only, hw8/src/scene.cpp:85-87,161-163; both
+ *                          stay in force).
+ * Both are RT_INTEGRATOR_HW8 / HW7 only (hw6 has the streams, not these options). */
 #define RT_FLAG_SAMPLE_SEEDS     4u
 #define RT_FLAG_RUSSIAN_ROULETTE 8u
 
@@ -182,7 +184,7 @@ typedef struct rt_render_params {
     void *stream;         /* hipStream_t to launch on, NULL = default stream */
     /* 0 or 1 = replay mode: one std::minstd_rand per pixel seeded y*W+x draws all of the pixel's samples, as the reference does
      * (hw8/src/sceneio.cpp:389-391) -- the mode every parity claim is made in.
-     * K > 1 = throughput mode (RT_INTEGRATOR_HW8 / HW7 only): K independent streams per pixel, stream k seeded
+     * K > 1 = throughput mode (RT_INTEGRATOR_HW8 / HW7 / HW6): K independent streams per pixel, stream k seeded
      * y*W+x + k*W*H and drawing samples/K samples (samples must be a multiple of K, W*H*K < 2^31-1); the same estimator
      * with decorrelated sub-streams, so a small frame or shard fills the GPU.  Deterministic, but NOT the reference's pixels:
      * it agrees with replay mode statistically only. */

@@ -347,6 +347,10 @@ void rto_hw6_bvh_stats(void *p, uint32_t *out4) {
     Scene *s = (Scene *)p;
     out4[0] = (uint32_t)s->bvh.nodes.size(); out4[1] = s->bvh.depth; out4[2] = (uint32_t)s->lbvh.nodes.size(); out4[3] = s->lbvh.depth;
 }
+// Test hook for throughput mode (rt_render_params.sample_streams): stream k of a pixel is the reference's per-pixel loop with the engine
+// seeded y*W+x + k*W*H instead of y*W+x (hw6/src/sceneio.cpp:280-284 seeds with y*W+x).
+static uint32_t g_seed_offset6 = 0;
+void rto_hw6_set_seed_offset(uint32_t off) { g_seed_offset6 = off; }
 int rto_hw6_render(void *p, int width, int height, int samples, int ray_depth, int x0, int y0, int w, int h, float *out_rgb, uint8_t *out8,
                    int nthreads, rto_counters *cnt) {
     Scene *s = (Scene *)p;
@@ -357,7 +361,7 @@ int rto_hw6_render(void *p, int width, int height, int samples, int ray_depth, i
     for (int j = 0; j < w * h; j++) {
         tl_cnt = Counters{};
         int x = x0 + j % w, y = y0 + j / w;
-        rng_t rng(y * width + x);                                                  // hw6/src/sceneio.cpp:280-284
+        rng_t rng((uint32_t)(y * width + x) + g_seed_offset6);                     // hw6/src/sceneio.cpp:280-284
         V3 px = s->get_pixel(rng, x, y);
         if (out_rgb) { out_rgb[3 * j] = px.x; out_rgb[3 * j + 1] = px.y; out_rgb[3 * j + 2] = px.z; }
         if (out8) to_extern(gamma_corrected(aces_tonemap(px)), out8 + 3 * j);

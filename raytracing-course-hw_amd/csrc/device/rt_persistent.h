@@ -44,9 +44,14 @@ namespace dev {
 // workgroup, five of which fill the CU's 160 KB (handed out in 1,280-byte granules: 25 granules each).
 #define P8_WAVES 4
 #define P8_THREADS (64 * P8_WAVES)
+#ifndef P8_PER_CU
 #define P8_PER_CU 5
+#endif
 #define P8_STACK 24                   // LDS traversal stack entries per lane; the walkers' tree is built at most this deep (rt_bvh_build.h)
-#define PT_MAX_PATHS 5120             // paths per workgroup (bitmap capacity in LDS): x 1,280 workgroups = 6.5 M (a 3840x2160 frame on one GPU: two passes)
+#ifndef PT_MAX_PATHS
+#define PT_MAX_PATHS 5120
+#endif
+#define PT_MAX_PATHS_NOTE             // paths per workgroup (bitmap capacity in LDS): x 1,280 workgroups = 6.5 M (a 3840x2160 frame on one GPU: two passes)
 #define PT_MIN_GROUP 16               // smallest group of the deal (group_shift 4): the LDS tables are sized for it
 #define PT_NW (PT_MAX_PATHS / 32)
 #define PT_BIT_T 1u                   // pending: closest-hit walk outstanding
@@ -79,7 +84,7 @@ struct PtShared {
     int cnt[16];
 };
 static_assert(PT_EXACT_BATCH * RT_STACK_SIZE <= P8_STACK * 64, "the exact role's stacks must fit the wave's LDS stack area");
-static_assert(sizeof(PtShared) <= 25 * 1280, "five workgroups per CU: 25 LDS granules of 1,280 bytes each");
+static_assert(sizeof(PtShared) <= (128 / P8_PER_CU) * 1280, "P8_PER_CU workgroups per CU: the CU's 128 LDS granules of 1,280 bytes shared evenly");
 
 struct PtParams {
     uint32_t n_groups;                // groups of this pass: 2^group_shift consecutive path slots each

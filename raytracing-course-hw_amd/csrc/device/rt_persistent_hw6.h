@@ -225,7 +225,7 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
             const F3 accum = f3(q3.x, q3.y, q3.z) + ret;
             sample++;
             int px, py; bool in_image; size_t out_index;
-            slot_to_pixel(R, slot + W.slot_base, px, py, in_image, out_index);
+            wf_slot_to_pixel(R, slot + W.slot_base, px, py, in_image, out_index);
             if (sample < (uint32_t)R.samples) {
                 F3 o, d;
                 p6_camera_ray(S, R, rng, px, py, o, d);
@@ -233,6 +233,11 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
                 r[1] = make_float4(d.y, d.z, __uint_as_float(rng.x), rng.saved);
                 r[3] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(p6_pack(0, rng.has_saved, sample, 0u)));
                 return sample < (uint32_t)R.sample_stop ? P6_TRACE : P6_PARKED;
+            }
+            if (R.streams > 1) { // throughput mode (rt_wavefront.h): this stream's unnormalised sum; wf_reduce_streams_kernel adds a pixel's streams
+                float *ps = R.partial + 3 * (size_t)(slot + W.slot_base);
+                ps[0] = accum.x; ps[1] = accum.y; ps[2] = accum.z;
+                return 0;
             }
             const F3 pxl = R.inv_samples * accum;                                               // scene.cpp:115
             if (R.out_rgb) { R.out_rgb[3 * out_index] = pxl.x; R.out_rgb[3 * out_index + 1] = pxl.y; R.out_rgb[3 * out_index + 2] = pxl.z; }
@@ -855,11 +860,11 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
         const uint32_t l = base + tid;
         bool started = false;
         if (l < wv.n_local) {
-            const uint32_t slot = pt_slot(sh, l);
+            const uint32_t slot = pt_slot(sh, l), gslot = slot + W.slot_base;
             int x, y; bool inside; size_t out_index;
-            slot_to_pixel(R, slot + W.slot_base, x, y, inside, out_index);
+            wf_slot_to_pixel(R, gslot, x, y, inside, out_index);
             if (!inside) {
-                if (R.shard_count > 1) { // padding of a border tile in the compact shard layout
+                if (R.shard_count > 1 && (R.streams <= 1 || gslot < R.n_pixslots)) { // padding of a border tile in the compact shard layout
                     if (R.out_rgb) { R.out_rgb[3 * out_index] = 0.f; R.out_rgb[3 * out_index + 1] = 0.f; R.out_rgb[3 * out_index + 2] = 0.f; }
                     if (R.out_rgb8) { R.out_rgb8[3 * out_index] = 0; R.out_rgb8[3 * out_index + 1] = 0; R.out_rgb8[3 * out_index + 2] = 0; }
                 }
@@ -870,7 +875,7 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
                 if (started) atomicOr(&sh.pending[l >> 4], PT_BIT_T << ((l & 15u) * 2u));
             } else {
                 Rng rng;
-                rng_seed(rng, (uint32_t)(y * R.width + x));
+                rng_seed(rng, (uint32_t)(y * R.width + x) + (R.streams > 1 ? (gslot / R.n_pixslots) * R.seed_stride : 0u)); // hw6/src/sceneio.cpp:280-284; throughput mode: stream k offset by k * W * H
                 F3 o, d;
                 p6_camera_ray(S, R, rng, x, y, o, d);
                 float4 *r = p6_rec(W, slot);

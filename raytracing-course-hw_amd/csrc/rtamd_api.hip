@@ -1038,7 +1038,8 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if ((p->flags & (RT_FLAG_SAMPLE_SEEDS | RT_FLAG_RUSSIAN_ROULETTE)) && streams <= 1)
             return fail(RT_ERR_INVALID_ARG, "rt_render: RT_FLAG_SAMPLE_SEEDS / RT_FLAG_RUSSIAN_ROULETTE change the estimator and belong to throughput mode (sample_streams > 1)");
         if (streams > 1) { // throughput mode (include/rtamd.h: sample_streams)
-            if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW7) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 is implemented for RT_INTEGRATOR_HW8 / HW7 only");
+            if (p->integrator != RT_INTEGRATOR_HW8 && p->integrator != RT_INTEGRATOR_HW7 && p->integrator != RT_INTEGRATOR_HW6) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 is implemented for RT_INTEGRATOR_HW6 / HW7 / HW8 only");
+            if (p->integrator == RT_INTEGRATOR_HW6 && (p->flags & (RT_FLAG_SAMPLE_SEEDS | RT_FLAG_RUSSIAN_ROULETTE))) return fail(RT_ERR_UNSUPPORTED, "rt_render: RT_FLAG_SAMPLE_SEEDS / RT_FLAG_RUSSIAN_ROULETTE are implemented for RT_INTEGRATOR_HW7 / HW8 only");
             if (streams > 256 || R.samples % streams != 0) return fail(RT_ERR_INVALID_ARG, "rt_render: samples must be a multiple of sample_streams (at most 256 streams)");
             if ((int64_t)R.width * R.height * streams >= 2147483647LL) return fail(RT_ERR_INVALID_ARG, "rt_render: width*height*sample_streams must stay below 2^31-1 (stream seeds)");
             if ((uint64_t)n_work * 64u * (uint64_t)streams >= 0x40000000ull) return fail(RT_ERR_LIMIT, "rt_render: too many path slots (pixels of this shard x sample_streams)");
@@ -1070,7 +1071,25 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
             const uint64_t auto_groups = (uint64_t)(getenv("RTAMD_AUTO_GROUPS_PER_CU") ? atoi(getenv("RTAMD_AUTO_GROUPS_PER_CU")) : 0);
             if (auto_groups && (uint64_t)n_work * (uint64_t)streams >= auto_groups * (uint64_t)scene->n_cus) use_persistent = false;
         }
-        if (streams > 1 && !use_wavefront) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 needs the wavefront kernels (RTAMD_KERNEL=mega or a tree beyond their limits is in effect)");
+        const bool hw6_persistent = scene->flavor == RT_INTEGRATOR_HW6 && scene->hw6_pt_stack && !(ksel && strcmp(ksel, "mega") == 0) && !getenv("RTAMD_HW6_SCRATCH_STACK");
+        if (streams > 1 && !use_wavefront && !hw6_persistent) return fail(RT_ERR_UNSUPPORTED, "rt_render: sample_streams > 1 needs the persistent / round kernels (RTAMD_KERNEL=mega or a tree beyond their limits is in effect)");
+        // throughput mode (include/rtamd.h: sample_streams): K path slots per pixel, `samples` per stream, a partial-sum buffer and a final reduction
+        auto setup_streams = [&]() {
+            R.streams = streams; R.n_pixslots = n_work * 64u; R.seed_stride = (uint32_t)R.width * (uint32_t)R.height;
+            R.total_samples = (uint32_t)R.samples;
+            R.sample_seeds = (p->flags & RT_FLAG_SAMPLE_SEEDS) ? 1u : 0u;
+            R.rr_depth = (p->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 2 : 0;
+            R.samples /= streams;                           // per stream; inv_samples stays 1 / (all samples of the pixel)
+            R.sample_stop = R.samples;
+            const size_t need = (size_t)streams * R.n_pixslots * 3 * sizeof(float);
+            if (scene->partial_bytes < need) {
+                if (scene->d_partial) (void)hipFree(scene->d_partial);
+                scene->d_partial = nullptr; scene->partial_bytes = 0;
+                HIP_CHECK(hipMalloc((void **)&scene->d_partial, need));
+                scene->partial_bytes = need;
+            }
+            R.partial = scene->d_partial;
+        };
         if (txt_scene && p->integrator == RT_INTEGRATOR_HW3 && R.ray_depth > RT3_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw3 ray_depth above 8");
         if (txt_scene && scene->txt_has_triangles && p->integrator != RT_INTEGRATOR_HW5) return fail(RT_ERR_INVALID_ARG, "rt_render: a .txt scene with TRIANGLE figures renders with RT_INTEGRATOR_HW5 only");
         if (p->integrator == RT_INTEGRATOR_HW5 && R.ray_depth > RT4_MAX_DEPTH) return fail(RT_ERR_LIMIT, "rt_render: hw5 ray_depth above 8");
@@ -1096,22 +1115,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         HIP_CHECK(hipEventRecord(scene->ev_start, stream));
         if (blocks) {
             if (use_wavefront) {
-                if (streams > 1) {
-                    R.streams = streams; R.n_pixslots = n_work * 64u; R.seed_stride = (uint32_t)R.width * (uint32_t)R.height;
-                    R.total_samples = (uint32_t)R.samples;
-                    R.sample_seeds = (p->flags & RT_FLAG_SAMPLE_SEEDS) ? 1u : 0u;
-                    R.rr_depth = (p->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 2 : 0;
-                    R.samples /= streams;                           // per stream; inv_samples stays 1 / (all samples of the pixel)
-                    R.sample_stop = R.samples;
-                    const size_t need = (size_t)streams * R.n_pixslots * 3 * sizeof(float);
-                    if (scene->partial_bytes < need) {
-                        if (scene->d_partial) (void)hipFree(scene->d_partial);
-                        scene->d_partial = nullptr; scene->partial_bytes = 0;
-                        HIP_CHECK(hipMalloc((void **)&scene->d_partial, need));
-                        scene->partial_bytes = need;
-                    }
-                    R.partial = scene->d_partial;
-                }
+                if (streams > 1) setup_streams();
                 // every traverse launch is bracketed by events when stats are wanted -- up to 64 k rounds (e.g. 10,922 spp at depth 6)
                 if (use_persistent) {
                     time_trace = stats != nullptr;
@@ -1148,12 +1152,18 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                 hipLaunchKernelGGL(dev::render_hw3_kernel, dim3(blocks), dim3(64), 0, stream, scene->viewt, R, txt_tan_fov_y, n_work);
                 HIP_CHECK(hipGetLastError());
                 launches = 1;
-            } else if (scene->flavor == RT_INTEGRATOR_HW6 && scene->hw6_pt_stack && !(ksel && strcmp(ksel, "mega") == 0) && !getenv("RTAMD_HW6_SCRATCH_STACK")) {
+            } else if (hw6_persistent) {
                 // persistent dataflow organisation (device/rt_persistent_hw6.h); RTAMD_KERNEL=mega keeps the per-lane path machine
                 use_persistent6 = true;
                 time_trace = stats != nullptr;
-                launch_persistent6(scene, scene->view6, R, n_work, stream, count, time_trace);
+                if (streams > 1) setup_streams();
+                launch_persistent6(scene, scene->view6, R, n_work * (uint32_t)streams, stream, count, time_trace);
                 launches = scene->pt_launches;
+                if (streams > 1) {
+                    hipLaunchKernelGGL(dev::wf_reduce_streams_kernel, dim3((R.n_pixslots + 255u) / 256u), dim3(256), 0, stream, R);
+                    HIP_CHECK(hipGetLastError());
+                    launches++;
+                }
             } else if (scene->flavor == RT_INTEGRATOR_HW6) {
                 if (scene->hw6_lds_stack && !getenv("RTAMD_HW6_SCRATCH_STACK")) hipLaunchKernelGGL(dev::render_hw6_kernel<true>, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);
                 else hipLaunchKernelGGL(dev::render_hw6_kernel<false>, dim3(blocks), dim3(64), 0, stream, scene->view6, R, n_work);

@@ -224,12 +224,17 @@ class Hw6Oracle:
             lib().rto_hw6_destroy(self._h)
             self._h = None
 
-    def render(self, width, height, samples, ray_depth=0, rect=None, threads=0):
+    def render(self, width, height, samples, ray_depth=0, rect=None, threads=0, seed_offset=0):
+        """seed_offset: engine of pixel i is seeded i + seed_offset (0 = the reference; k*W*H = stream k of throughput mode)."""
         x0, y0, w, h = rect if rect else (0, 0, width, height)
         rgb = np.zeros((h, w, 3), np.float32)
         rgb8 = np.zeros((h, w, 3), np.uint8)
         cnt = Counters()
-        lib().rto_hw6_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads, C.byref(cnt))
+        lib().rto_hw6_set_seed_offset(C.c_uint32(seed_offset))
+        try:
+            lib().rto_hw6_render(self._h, width, height, samples, ray_depth, x0, y0, w, h, rgb.ctypes.data, rgb8.ctypes.data, threads, C.byref(cnt))
+        finally:
+            lib().rto_hw6_set_seed_offset(C.c_uint32(0))
         return rgb, rgb8, cnt
 
     def light_order(self):

@@ -84,9 +84,42 @@ def test_throughput_mode_rejects_what_it_cannot_do(rt, sphere_scene):
         scene.render(16, 16, 1024, sample_streams=512)   # more than 256 streams
     scene.close()
     s6 = rt.Scene(pin_cases.hw6_soup())
-    with pytest.raises(rt.RtError):
-        s6.render(16, 16, 4, integrator=rt.RT_INTEGRATOR_HW6, sample_streams=2)
+    with pytest.raises(rt.RtError):   # hw6 has the streams, not the other estimator options
+        s6.render(16, 16, 4, integrator=rt.RT_INTEGRATOR_HW6, sample_streams=2, flags=rt.RT_FLAG_SAMPLE_SEEDS)
     s6.close()
+
+
+@pytest.mark.parametrize("name", ["practice6_1", "hw6_soup"])
+def test_hw6_streams_are_replays_with_an_offset_seed(rt, name):
+    """Throughput mode for the hw6 integrator (hw6/src/scene.cpp:47-105, seeding hw6/src/sceneio.cpp:280-284): stream k of a pixel is the
+    reference's per-pixel loop with the engine seeded y*W+x + k*W*H; the oracle composes the K replays through its seed-offset hook.
+    Also: one stream is replay mode itself, shards assemble to the frame, and the render is deterministic."""
+    sd = pin_cases.HW6_CASES[name][0]()
+    w, h, spp, k = 56, 40, 12, 4
+    scene = rt.Scene(sd)
+    rgb, rgb8, st = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6, sample_streams=k)
+    orc = oracle_lib.Hw6Oracle(sd)
+    per = spp // k
+    total = np.zeros((h, w, 3), np.float32)
+    for i in range(k):
+        part, _, _ = orc.render(w, h, per, seed_offset=i * w * h)
+        total = total + part * np.float32(per)
+    ref = total * np.float32(1.0 / spp)
+    err = np.abs(rgb.astype(np.float64) - ref)
+    print(f"hw6 {name}: K={k} max |gpu - composed oracle| {err.max():.2e}, pipeline {st.pipeline}")
+    assert np.all(err <= 2e-6 * np.maximum(1.0, np.abs(ref))) and st.samples == w * h * spp and st.pipeline == rt.RT_PIPELINE_PERSISTENT
+    a, a8, _ = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6)
+    b, b8, _ = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6, sample_streams=1)
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a8, b8) and not np.array_equal(a, rgb, equal_nan=True)
+    again, _, _ = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6, sample_streams=k)
+    assert np.array_equal(again, rgb, equal_nan=True)
+    acc = np.zeros_like(rgb)
+    for r in range(3):
+        p = rt.make_params(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6, shard_index=r, shard_count=3, tile=16, sample_streams=k)
+        buf, _, _ = scene.render(w, h, spp, integrator=rt.RT_INTEGRATOR_HW6, shard_index=r, shard_count=3, tile=16, sample_streams=k, want_rgb8=False)
+        acc += rt.unshard(p, buf)
+    assert np.array_equal(acc, rgb)
+    scene.close()
 
 
 def test_russian_roulette_and_per_sample_seeds(rt, sphere_scene):

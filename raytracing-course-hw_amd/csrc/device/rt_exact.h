@@ -210,9 +210,12 @@ RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2
 
 // light_pdf_one (rt_device.h) that also says whether the hit is robust against the reference's box tests (pt_box_robust on
 // the light triangle's own box: a, a + b, a + c).
-RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d, bool &last, bool &robust) {
+// `index`: the light's position in the reference's light order — carried by the record itself (pad >> 1) in the persistent kernel's own light
+// tree (SceneView::lights_walk), whose leaf order is not the light order.
+RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d, bool &last, bool &robust, uint32_t &index) {
     TriIsect T = load_isect(&L->isect);
-    last = T.pad != 0;
+    last = (T.pad & 1u) != 0;
+    index = T.pad >> 1;
     robust = true;
     float t, u, v; bool inside;
     if (!tri_test(T, x, d, t, u, v, inside)) return 0.f;

@@ -399,7 +399,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) { prof.light_iters++; prof.light_lane_iters += __popcll(__ballot(inner)); }
             if (inner) {
-                const float4 *q = reinterpret_cast<const float4 *>(S.light_nodes + cur);
+                const float4 *q = reinterpret_cast<const float4 *>(S.light_walk_nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 steps++;
@@ -418,13 +418,21 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (cur != RT_EMPTY_LEAF) {
                 uint32_t i = cur & ~RT_LEAF_BIT;
                 for (;;) {
-                    bool last, robust;
+                    bool last, robust; uint32_t li;
                     if (COUNT) n_tris++;
                     steps++;
-                    float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust);
+                    float term = pt_light_pdf_one(S, S.lights_walk + i, o, d, last, robust, li);
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
                         if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= P8_STACK) overflow = true;
-                        else { stack[P8_STACK - 1 - 2 * k][lane] = i; stack[P8_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }
+                        else { // kept sorted by light index (this tree's leaf order is not the light order): hit j at words P8_STACK-1-2j (index), -2-2j (term)
+                            int j = k;
+                            while (j > 0 && stack[P8_STACK - 1 - 2 * (j - 1)][lane] > li) {
+                                stack[P8_STACK - 1 - 2 * j][lane] = stack[P8_STACK - 1 - 2 * (j - 1)][lane];
+                                stack[P8_STACK - 2 - 2 * j][lane] = stack[P8_STACK - 2 - 2 * (j - 1)][lane];
+                                j--;
+                            }
+                            stack[P8_STACK - 1 - 2 * j][lane] = li; stack[P8_STACK - 2 - 2 * j][lane] = __float_as_uint(term); k++;
+                        }
                     }
                     if (last) break;
                     i++;

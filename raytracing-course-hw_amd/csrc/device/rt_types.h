@@ -86,6 +86,11 @@ struct SceneView {
     const TriShade *tri_shade;
     const GpuNode *light_nodes;    // light BVH in the reference's topology, root = 0
     const LightRec *lights;
+    // The persistent kernel's light walker: a tree of the library's own over the lights (GPU-built over their reference leaf boxes) and the light
+    // records in ITS leaf order, pad = light index (position in `lights`) << 1 | last-of-leaf.  == light_nodes / lights with pads rewritten when the
+    // scene has too few lights to bother (then the index is the position).
+    const GpuNode *light_walk_nodes;
+    const LightRec *lights_walk;
     const uint16_t *light_sep;     // range-minimum table of the separation depths of neighbouring lights (scene_prep.h)
     const GpuMaterial *materials;
     const GpuImage *images;

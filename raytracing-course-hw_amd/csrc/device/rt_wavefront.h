@@ -575,9 +575,9 @@ RT_DEV void wf_light_loop_lean(const SceneView &S, const WfView &W, uint32_t (*s
             if (cur != RT_EMPTY_LEAF) {
                 uint32_t i = cur & ~RT_LEAF_BIT;
                 for (;;) {
-                    bool last, robust;
+                    bool last, robust; uint32_t li;
                     if (COUNT) n_tris++;
-                    float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust);
+                    float term = pt_light_pdf_one(S, S.lights + i, o, d, last, robust, li); // the reference topology over `lights`: the position i IS the light index (li is not used)
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
                         if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= WF_STACK) overflow = true; // not robust against the reference's box tests: exact walk
                         else { stack[WF_STACK - 1 - 2 * k][lane] = i; stack[WF_STACK - 2 - 2 * k][lane] = __float_as_uint(term); k++; }

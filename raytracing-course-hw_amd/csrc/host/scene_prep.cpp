@@ -362,6 +362,11 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
     encode_tree(light_builder.nodes, out.light_nodes, light_leaf_last, out.box_pad);
     encode_ref_tree(light_builder.nodes, out.ref_light_nodes);
     build_light_sep(light_builder.nodes, n_lights, out.light_sep, out.light_sep_levels);
+    out.light_walk_box.assign((size_t)(n_lights ? n_lights : 1) * 8, 0.f);
+    for (const RefNode &rn : light_builder.nodes)
+        if (rn.left == 0)
+            for (uint32_t i = rn.first; i < rn.last; i++)
+                for (int k = 0; k < 3; k++) { out.light_walk_box[8 * (size_t)i + k] = rn.box.lo[k]; out.light_walk_box[8 * (size_t)i + 4 + k] = rn.box.hi[k]; }
     out.light_order.assign(lorder.begin(), lorder.begin() + n_lights);
 
     // ---- 3. records ---------------------------------------------------------------------------------

@@ -18,6 +18,10 @@ struct PreparedScene {
     // walkers' tree from, so that whatever the reference can reach through its leaf box is inside a box of ours.  Empty when the
     // reference's tree is not replayed.
     std::vector<float> walk_box;
+    // The same for the lights (light order): the box of each light's leaf in the reference's light tree.  The persistent kernel's light
+    // walker uses a tree of its own over these (built on the GPU): the reference's light tree also holds the far-apart ceiling quads and
+    // the lamp near its root, so its upper boxes span the room and most rays descend into them in vain.
+    std::vector<float> light_walk_box;
     float box_c2 = 0.f;
     float box_pad = 0.f;   // absolute part of the walkers' box padding (scene_prep.cpp pad_box): 2^-18 x the largest |coordinate|
     // Order of the light-pdf additions without walking the reference tree: light_sep[j * n_lights + i] = the shallowest

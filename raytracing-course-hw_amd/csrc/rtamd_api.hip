@@ -78,6 +78,7 @@ struct rt_scene {
     bool txt_has_triangles = false; // TRIANGLE figures exist only in the hw5 grammar: such a scene renders with RT_INTEGRATOR_HW5 only
     int flavor = RT_INTEGRATOR_HW8; // which integrator this scene was prepared for
     bool hw6_lds_stack = false, hw6_pt_stack = false;
+    uint32_t light_walk_depth = 0;   // hw8: depth of the tree the persistent kernel's light walker uses
     std::vector<void *> allocations;
     rt_scene_info info{};
     std::vector<uint32_t> light_order;
@@ -386,6 +387,38 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
         V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || fast_build) ? 0u : 1u; // RT_BUILD_DEVICE_BVH: there is no reference tree to be exact about
         if (getenv("RTAMD_DIAG_LOOKBEHIND_ONLY")) V.exact_boxes = 2u; // diagnostic (timing only, pixels NOT exact): the walkers look behind as with the gate, every hit stands
         V.lights = keep(upload(P.lights, bytes));
+        {   // the light walker's own tree (rt_types.h: light_walk_nodes / lights_walk)
+            const uint32_t nl = (uint32_t)P.lights.size();
+            std::vector<LightRec> tagged = P.lights; // pad = light index << 1 | last-of-leaf (of the REFERENCE topology for now)
+            for (uint32_t i = 0; i < nl; i++) tagged[i].isect.pad = (i << 1) | (tagged[i].isect.pad ? 1u : 0u);
+            bool own_tree = nl >= 64 && !getenv("RTAMD_HOST_LIGHT_BVH");
+            if (own_tree) {
+                LightRec *d_tagged = upload(tagged, bytes);
+                uint64_t scratch = 0;
+                float *d_lbox = upload(P.light_walk_box, scratch);
+                DeviceTree lt;
+                LightRec *d_walk = nullptr;
+                try {
+                    lt = build_tree_on_device(d_lbox, nl, P.box_pad, 16); // the hits of a walk share its 24-entry column with the node stack
+                    HIP_CHECK(hipMalloc((void **)&d_walk, (size_t)nl * sizeof(LightRec)));
+                    gather_records(d_tagged, d_walk, lt, nl, sizeof(LightRec), 11, true); // word 11 = TriIsect::pad
+                    HIP_CHECK(hipDeviceSynchronize());
+                } catch (...) {
+                    (void)hipFree(d_lbox); (void)hipFree(d_tagged); if (d_walk) (void)hipFree(d_walk);
+                    free_device_tree(lt);
+                    throw;
+                }
+                (void)hipFree(d_lbox); (void)hipFree(d_tagged);
+                (void)hipFree(lt.order); (void)hipFree(lt.last); lt.order = nullptr; lt.last = nullptr;
+                V.light_walk_nodes = keep(lt.nodes); V.lights_walk = keep(d_walk);
+                bytes += (uint64_t)lt.n_nodes * sizeof(GpuNode);
+                s->light_walk_depth = lt.depth;
+            } else {
+                V.light_walk_nodes = V.light_nodes;
+                V.lights_walk = keep(upload(tagged, bytes));
+                s->light_walk_depth = P.light_bvh_depth;
+            }
+        }
         V.materials = keep(upload(P.materials, bytes));
         V.images = keep(upload(P.images, bytes));
         V.texels = keep(upload(P.texels, bytes));
@@ -1066,7 +1099,7 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         // tree takes ~1.5 ms; RTAMD_ROUNDS_EXACT=1 switches them on for testing).  RTAMD_AUTO_GROUPS_PER_CU=n: opt into the round
         // pipeline from n sub-tiles per CU on.
         bool use_persistent = use_wavefront && !(ksel && strcmp(ksel, "wavefront") == 0) &&
-                              scene->info.bvh_depth <= P8_STACK && scene->info.light_bvh_depth <= P8_STACK && !getenv("RTAMD_WF_LDS_STACK");
+                              scene->info.bvh_depth <= P8_STACK && scene->light_walk_depth <= P8_STACK && !getenv("RTAMD_WF_LDS_STACK");
         if (use_persistent && !ksel) {
             const uint64_t auto_groups = (uint64_t)(getenv("RTAMD_AUTO_GROUPS_PER_CU") ? atoi(getenv("RTAMD_AUTO_GROUPS_PER_CU")) : 0);
             if (auto_groups && (uint64_t)n_work * (uint64_t)streams >= auto_groups * (uint64_t)scene->n_cus) use_persistent = false;

@@ -216,6 +216,33 @@ RT_DEV bool slab_test(float4 lo, float4 hi, const RayInv &r, float tbest, float 
     return (tmin <= tmax) & (tmax >= 0.f) & (tmin <= tbest);
 }
 
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
+// The walk nodes on the 16-bit grid (rt_types.h GpuNode4Q).  The ray moves into grid coordinates once per walk,
+//     o' = (o - grid.lo) / step,   1/d' = step / d      (t keeps its meaning: x = o + t d  <=>  x' = o' + t d'),
+// and a child's slabs are (cell - o') * (1/d'): cells are small integers, exact in a float.  What rounds: o' — three roundings, at most
+// 3 * 2^-24 * 65,536 = 0.012 cells for an origin inside the grid (the grid covers the scene's boxes and the camera, so every ray origin)
+// — and relative errors of the subtraction, of 1/d' (two roundings beside the reciprocal's) and of the product, 5 * 2^-24 of a
+// slab's t: since origin and box both lie on the grid, that t is at most 65,536 cells' worth along its axis, so 0.02 cells.  The extra
+// cell on either side of every box (rt_node_grid.h grid_axis_word) covers both, and the interval needs no widening of its own.
+struct RayGrid { float ox, oy, oz, ix, iy, iz; };
+RT_DEV RayGrid make_ray_grid(const NodeGrid &G, F3 o, F3 d) {
+    const RayInv r = make_ray_inv(o, d);
+    RayGrid g;
+    g.ox = (o.x - G.lo[0]) * G.istep[0]; g.oy = (o.y - G.lo[1]) * G.istep[1]; g.oz = (o.z - G.lo[2]) * G.istep[2];
+    g.ix = G.step[0] * r.inv.x; g.iy = G.step[1] * r.inv.y; g.iz = G.step[2] * r.inv.z;
+    return g;
+}
+// b = one child record of a GpuNode4Q: x, y, z words (lo | hi << 16) and the child word.  Pairs (lo, hi) per axis: packed subtract and multiply.
+RT_DEV bool slab_test_q(uint4 b, const RayGrid &r, float tbest, float &tnear) {
+    const rt_f2 x = (rt_f2{(float)(b.x & 0xFFFFu), (float)(b.x >> 16)} - r.ox) * r.ix;
+    const rt_f2 y = (rt_f2{(float)(b.y & 0xFFFFu), (float)(b.y >> 16)} - r.oy) * r.iy;
+    const rt_f2 z = (rt_f2{(float)(b.z & 0xFFFFu), (float)(b.z >> 16)} - r.oz) * r.iz;
+    const float tmin = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
+    const float tmax = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
+    tnear = tmin;
+    return (tmin <= tmax) & (tmax >= 0.f) & (tmin <= tbest);
+}
+
 #define RT_LEAF_BIT 0x80000000u
 #define RT_EMPTY_LEAF 0xFFFFFFFFu
 #define RT_STACK_SIZE 64
@@ -230,7 +257,8 @@ struct Counters { unsigned long long closest, lightq, nodes, tris; };
 
 // Closest hit with the reference's tie rule: smallest t, equal t -> lowest figure index
 // (bvh.h:111-142 visits figures in increasing index order and replaces only on strict '<').
-template <bool COUNT>
+// STRIDE: distance in words between consecutive stack entries (1 = a private array; see ref_closest_hit, rt_exact.h)
+template <bool COUNT, int STRIDE = 1>
 RT_DEV HitRec closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, Counters &cnt) {
     HitRec best;
     best.idx = -1; best.t = RT_T_MAX; best.u = 0.f; best.v = 0.f; best.inside = false;
@@ -249,7 +277,7 @@ RT_DEV HitRec closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, Count
             uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
             if (h0 & h1) {
                 bool swap = n1 < n0;
-                stack[sp++] = swap ? c0 : c1;
+                stack[STRIDE * sp++] = swap ? c0 : c1;
                 cur = swap ? c1 : c0;
                 continue;
             }
@@ -270,7 +298,7 @@ RT_DEV HitRec closest_hit(const SceneView &S, F3 o, F3 d, uint32_t *stack, Count
             }
         }
         if (sp == 0) break;
-        cur = stack[--sp];
+        cur = stack[STRIDE * --sp];
     }
     return best;
 }

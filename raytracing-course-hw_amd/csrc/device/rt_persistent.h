@@ -69,10 +69,93 @@ namespace dev {
 #define PT_GSHIFT 15                  // cnt only: PtParams::group_shift (constant during the launch)
 // What a sub-tile costs its workgroup, in units of one closest-hit node step (wave time by role over steps by role on the benchmark
 // scene): the measure the frame is re-dealt by after its first phase.  Counting shaded hits alone misses the rays that hit nothing.
-#define PT_COST_TRACE_STEP 1u
-#define PT_COST_LIGHT_STEP 2u
+#ifndef PT_COST_TRACE_NODE
+#define PT_COST_TRACE_NODE 1u     // a node visit of a closest-hit walk
+#endif
+#define PT_COST_TRACE_TRI 1u      // a triangle test of a closest-hit walk
+#ifndef PT_COST_LIGHT_NODE
+#define PT_COST_LIGHT_NODE 2u     // a node visit of a light-sum walk
+#endif
+#define PT_COST_LIGHT_TEST 2u     // a light test of a light-sum walk
 #define PT_COST_SHADE 14u
 #define PT_DEBUG_BLOCKS 2048           // RTAMD_DEBUG_COUNTERS: workgroups whose start / exit times are recorded (>= 256 CUs x 5)
+#ifndef PT_QUANT_NODES
+#define PT_QUANT_NODES 1       // the walkers read the four-wide grid nodes (rt_types.h GpuNode4Q: two levels per fetch); 0 = the two-box float nodes, for A/B builds
+#endif
+#define PT_T_OVERFLOW (-1.f)          // t of a closest-hit record whose walk ran out of stack: the exact role redoes the query
+// ---- one step of a walk over the four-wide grid nodes (rt_types.h GpuNode4Q), shared with rt_persistent_hw6.h ------------------------
+#define PT_WIDE_NONE 0                // no child entered: the caller pops its stack
+#define PT_WIDE_WENT 1                // `cur` is the child to visit next, the others wait in the lane's stack column
+#define PT_WIDE_FULL 2                // the column cannot take the children that would wait (nothing was pushed, `cur` unchanged)
+// sort key of a child's entry distance: the bits of max(t, 0) (a negative float, -0 included, is a negative integer)
+RT_DEV uint32_t pt_near_key(float t) { const int b = (int)__float_as_uint(t); return (uint32_t)(b > 0 ? b : 0); }
+// compare-exchange of (key, child word) pairs: the smaller key first
+RT_DEV void pt_order(uint32_t &ka, uint32_t &ca, uint32_t &kb, uint32_t &cb) {
+    const bool s = kb < ka;
+    const uint32_t k = s ? kb : ka, c = s ? cb : ca;
+    kb = s ? ka : kb; cb = s ? ca : cb;
+    ka = k; ca = c;
+}
+// Closest-hit walks: the entered children nearest first — the nearest becomes `cur`, the others are pushed farthest first.
+// `cap`: entries the column may hold.
+RT_DEV int pt_wide_step_nearest(const GpuNode4Q *nodes, const RayGrid &ray, float cull_t, uint32_t (*stack)[64], int lane, int &sp, int cap, uint32_t &cur) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(nodes + cur);
+    const uint4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3];
+    float n0, n1, n2, n3;
+    const bool h0 = slab_test_q(b0, ray, cull_t, n0), h1 = slab_test_q(b1, ray, cull_t, n1);
+    const bool h2 = slab_test_q(b2, ray, cull_t, n2), h3 = slab_test_q(b3, ray, cull_t, n3);
+    uint32_t k0 = h0 ? pt_near_key(n0) : 0xFFFFFFFFu, k1 = h1 ? pt_near_key(n1) : 0xFFFFFFFFu;
+    uint32_t k2 = h2 ? pt_near_key(n2) : 0xFFFFFFFFu, k3 = h3 ? pt_near_key(n3) : 0xFFFFFFFFu;
+    uint32_t c0 = b0.w, c1 = b1.w, c2 = b2.w, c3 = b3.w;
+#ifndef PT_WIDE_SORT
+#define PT_WIDE_SORT 1
+#endif
+#if PT_WIDE_SORT
+    pt_order(k0, c0, k1, c1); pt_order(k2, c2, k3, c3); pt_order(k0, c0, k2, c2); pt_order(k1, c1, k3, c3); pt_order(k1, c1, k2, c2);
+#else
+    pt_order(k0, c0, k1, c1); pt_order(k2, c2, k3, c3); pt_order(k0, c0, k2, c2); // only the nearest is singled out; the others wait in any order
+#endif
+    const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (nh == 0) return PT_WIDE_NONE;
+    if (sp + nh - 1 > cap) return PT_WIDE_FULL;
+#if PT_WIDE_SORT
+    if (nh > 3) stack[sp++][lane] = c3;
+    if (nh > 2) stack[sp++][lane] = c2;
+    if (nh > 1) stack[sp++][lane] = c1;
+#else
+    if (k3 != 0xFFFFFFFFu) stack[sp++][lane] = c3;
+    if (k2 != 0xFFFFFFFFu) stack[sp++][lane] = c2;
+    if (k1 != 0xFFFFFFFFu) stack[sp++][lane] = c1;
+#endif
+    cur = c0;
+    return PT_WIDE_WENT;
+}
+// Light sums: every entered child is walked, in any order (the callers keep their hits sorted): the first one now, the others wait.
+RT_DEV int pt_wide_step_all(const GpuNode4Q *nodes, const RayGrid &ray, uint32_t (*stack)[64], int lane, int &sp, int cap, uint32_t &cur) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(nodes + cur);
+    const uint4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3];
+    float n;
+    const bool h0 = slab_test_q(b0, ray, RT_T_MAX, n), h1 = slab_test_q(b1, ray, RT_T_MAX, n);
+    const bool h2 = slab_test_q(b2, ray, RT_T_MAX, n), h3 = slab_test_q(b3, ray, RT_T_MAX, n);
+    const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (nh == 0) return PT_WIDE_NONE;
+    if (sp + nh - 1 > cap) return PT_WIDE_FULL;
+    const int first = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+    if (h3 && first != 3) stack[sp++][lane] = b3.w;
+    if (h2 && first < 2) stack[sp++][lane] = b2.w;
+    if (h1 && first < 1) stack[sp++][lane] = b1.w;
+    cur = first == 0 ? b0.w : first == 1 ? b1.w : first == 2 ? b2.w : b3.w;
+    return PT_WIDE_WENT;
+}
+#if PT_QUANT_NODES
+typedef RayGrid PtRay;
+#define PT_RAY_IDLE {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}
+RT_DEV PtRay pt_make_ray(const SceneView &S, F3 o, F3 d) { return make_ray_grid(S.grid, o, d); }
+#else
+typedef RayInv PtRay;
+#define PT_RAY_IDLE {{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}}
+RT_DEV PtRay pt_make_ray(const SceneView &, F3 o, F3 d) { return make_ray_inv(o, d); }
+#endif
 #define PT_EXACT_BATCH 16             // the exact role walks at most this many queries at once: their stacks (RT_STACK_SIZE entries each) share the wave's LDS stack area
 
 struct PtShared {
@@ -224,14 +307,14 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     int sp = 0;
     uint32_t steps = 0;   // node steps + triangle tests of the lane's current walk: the cost measure of the re-deal (PT_COST_*)
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayInv ray = make_ray_inv(o, d);
+    PtRay ray = PT_RAY_IDLE; // idle lanes: never used
     float best_t = RT_T_MAX, best_u = 0.f, best_v = 0.f;
     // Boxes are pruned, and farther hits dropped, only beyond cull_t = best_t + the look-behind of rt_exact.h: the runner-up of the
     // best hit must be SEEN, whatever tree the walk uses, to decide at the end of the walk whether the exact walk is needed.
     float cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // h_ray: absolute part of the look-behind (pt_look_behind)
     auto store_hit = [&]() { // the gate (pt_shade_item) decides with the runner-up's t whether this hit needs the exact walk
         wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(S.exact_boxes && hit != WF_MISS ? hit | pt_gap_code(best_t, t2) : hit));
-        if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * PT_COST_TRACE_STEP);
+        if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps);
     };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -254,7 +337,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     const float4 *r = wf_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
-                    ray = make_ray_inv(o, d);
+                    ray = pt_make_ray(S, o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     steps = 0;
                     cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
@@ -270,11 +353,24 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) { prof.trace_iters++; prof.trace_lane_iters += __popcll(__ballot(inner)); }
             if (inner) {
+                if (COUNT) n_nodes++;
+                steps += PT_COST_TRACE_NODE;
+#if PT_QUANT_NODES
+                const int went = pt_wide_step_nearest(S.nodes4, ray, cull_t, stack, lane, sp, P8_STACK, cur);
+                if (went == PT_WIDE_NONE) {
+                    if (sp == 0) { store_hit(); active = false; fin = l; }
+                    else cur = stack[--sp][lane];
+                } else if (went == PT_WIDE_FULL) {
+                    // The column is full (a walk holds up to three entries per level of a tree of up to P8_STACK / 2 levels; this takes a
+                    // ray that grazes many boxes: triangle soups).  The walk ends here and says so — no hit has a negative t — and the
+                    // exact role walks the query with a stack of its own (pt_exact_batch).
+                    best_t = PT_T_OVERFLOW; best_u = 0.f; best_v = 0.f; hit = 0u; t2 = PT_T_OVERFLOW;
+                    store_hit(); active = false; fin = l;
+                }
+#else
+                float n0, n1;
                 const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
-                if (COUNT) n_nodes++;
-                steps++;
-                float n0, n1;
                 bool h0 = slab_test(lo0, hi0, ray, cull_t, n0);
                 bool h1 = slab_test(lo1, hi1, ray, cull_t, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
@@ -288,6 +384,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     store_hit();
                     active = false; fin = l;
                 } else cur = stack[--sp][lane];
+#endif
             }
         }
         if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
@@ -296,7 +393,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 for (;;) {
                     TriIsect T = load_isect(S.tri_walk + i);
                     if (COUNT) n_tris++;
-                    steps++;
+                    steps += PT_COST_TRACE_TRI;
                     float t, u, v; bool inside;
                     const uint32_t fi = T.pad >> 1; // index in the figure order
                     if (tri_test_closer(T, o, d, cull_t, t, u, v, inside)) {
@@ -329,10 +426,10 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     int sp = 0, k = 0;
     uint32_t steps = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayInv ray = make_ray_inv(o, d);
+    PtRay ray = PT_RAY_IDLE; // idle lanes: never used
     auto finish = [&]() {
         active = false;
-        if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * PT_COST_LIGHT_STEP);
+        if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps);
         if (overflow) { fin = l | 0x80000000u; return; }
         float v = 0.f;
         if (k == 1) v = __uint_as_float(stack[P8_STACK - 2][lane]);
@@ -385,7 +482,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     const float4 *r = wf_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
-                    ray = make_ray_inv(o, d);
+                    ray = pt_make_ray(S, o, d);
                     cur = 0; sp = 0; k = 0; overflow = false; steps = 0;
                     active = true;
                 }
@@ -399,11 +496,18 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) { prof.light_iters++; prof.light_lane_iters += __popcll(__ballot(inner)); }
             if (inner) {
+                if (COUNT) n_nodes++;
+                steps += PT_COST_LIGHT_NODE;
+#if PT_QUANT_NODES
+                const int went = pt_wide_step_all(S.light_walk_nodes4, ray, stack, lane, sp, P8_STACK - 2 * k - 1, cur); // the hits sit at the column's top
+                if (went == PT_WIDE_NONE) {
+                    if (sp == 0) finish();
+                    else cur = stack[--sp][lane];
+                } else if (went == PT_WIDE_FULL) { overflow = true; finish(); } // no room beside the hits: the slow role sums this query
+#else
+                float n0, n1;
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_walk_nodes + cur);
                 float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
-                if (COUNT) n_nodes++;
-                steps++;
-                float n0, n1;
                 bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
                 bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
                 uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
@@ -412,6 +516,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 else if (h1) cur = c1;
                 else if (sp == 0) finish();
                 else cur = stack[--sp][lane];
+#endif
             }
         }
         if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
@@ -420,7 +525,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 for (;;) {
                     bool last, robust; uint32_t li;
                     if (COUNT) n_tris++;
-                    steps++;
+                    steps += PT_COST_LIGHT_TEST;
                     float term = pt_light_pdf_one(S, S.lights_walk + i, o, d, last, robust, li);
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
                         if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= P8_STACK) overflow = true;
@@ -491,6 +596,7 @@ RT_DEV int pt_shade_lean(const SceneView &S, const RenderView &R, const WfView &
     float4 pe0, pe1;
     { const float4 *e = wf_entry(W, slot, depth); pe0 = e[0]; pe1 = e[1]; }
     // the exactness gate (pt_shade_item): a hit that does not stand as the reference's answer goes to the exact walk first, untouched
+    if (q2.x == PT_T_OVERFLOW && !(packed & WF_VERIFIED_BIT)) return PT_SHADE_EXACT; // the walk ran out of stack (pt_trace_stint)
     if (S.exact_boxes == 1u && hit != WF_MISS && !(packed & WF_VERIFIED_BIT) &&
         !pt_hit_stands(f3(blo.x, blo.y, blo.z), f3(bhi.x, bhi.y, bhi.z), f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), q2.x, pt_gap_floor(hit, q2.x), S.box_c2, S.box_c2x, S.cull_k))
         return PT_SHADE_EXACT;
@@ -637,7 +743,12 @@ RT_DEV void pt_exact_batch(const SceneView &S, const WfView &W, SH &sh, PtWave &
         float4 *r = wf_rec(W, slot);
         float4 q0 = r[0], q1 = r[1];
         float bt, bu, bv; uint32_t hit;
-        ref_closest_hit<PT_EXACT_BATCH>(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, bt, bu, bv, hit);
+        if (S.exact_boxes == 1u) ref_closest_hit<PT_EXACT_BATCH>(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, bt, bu, bv, hit);
+        else { // no reference boxes to be exact about (a walk that ran out of stack): the padded float boxes of the two-box tree decide, as for every other hit
+            Counters c; c.closest = c.lightq = c.nodes = c.tris = 0;
+            const HitRec h = closest_hit<false, PT_EXACT_BATCH>(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), xstack, c);
+            bt = h.t; bu = h.u; bv = h.v; hit = h.idx < 0 ? WF_MISS : ((uint32_t)h.idx | (h.inside ? WF_INSIDE_BIT : 0u));
+        }
         r[2] = make_float4(bt, bu, bv, __uint_as_float(hit));
         float *pk = reinterpret_cast<float *>(r + 3) + 3;
         *pk = __uint_as_float(__float_as_uint(*pk) | WF_VERIFIED_BIT);

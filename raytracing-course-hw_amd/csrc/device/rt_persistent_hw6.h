@@ -104,6 +104,7 @@ RT_DEV int p6_advance(const SceneView6 &S, const RenderView &R, const W6View &W,
     int fp = (int)(packed & 15u);
     rng.has_saved = (packed & 16u) != 0;
     uint32_t sample = packed >> 8;
+    if (!(packed & (P6_LIGHT_ONLY | P6_VERIFIED)) && r[2].x == PT_T_OVERFLOW) return P6_EXACT; // the walk ran out of stack (p6_trace_stint)
     if (S.exact_boxes && !(packed & (P6_LIGHT_ONLY | P6_VERIFIED))) {
         // the gate of rt_exact.h (pt_hit_stands), before anything of the path's state changes
         const float4 g0 = r[0], g2 = r[2];
@@ -296,7 +297,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     int sp = 0;
     uint32_t steps = 0; // node steps + triangle tests of the lane's walk: the cost measure of the re-deal
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayInv ray = make_ray_inv(o, d);
+    RayGrid ray = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}; // idle lanes: never used
     float best_t = RT_T_MAX, cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // look-behind and runner-up: rt_exact.h
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -317,7 +318,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     const float4 *r = p6_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
-                    ray = make_ray_inv(o, d);
+                    ray = make_ray_grid(S.grid, o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     steps = 0;
                     cur = 0; sp = 0; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
@@ -332,22 +333,15 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (inner) {
-                const float4 *q = reinterpret_cast<const float4 *>(S.nodes + cur);
-                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 steps++;
-                float n0, n1;
-                bool h0 = slab_test(lo0, hi0, ray, cull_t, n0);
-                bool h1 = slab_test(lo1, hi1, ray, cull_t, n1);
-                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-                if (h0 & h1) { bool swap = n1 < n0; stack[sp++][lane] = swap ? c0 : c1; cur = swap ? c1 : c0; }
-                else if (h0) cur = c0;
-                else if (h1) cur = c1;
-                else if (sp == 0) {
+                const int went = pt_wide_step_nearest(S.nodes4, ray, cull_t, stack, lane, sp, P6_STACK, cur);
+                if (went == PT_WIDE_FULL) { best_t = PT_T_OVERFLOW; hit = 0u; t2 = PT_T_OVERFLOW; best_inside = false; } // the exact role redoes the query (rt_persistent.h)
+                if (went == PT_WIDE_FULL || (went == PT_WIDE_NONE && sp == 0)) {
                     p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
                     if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_TRACE_STEP);
                     active = false; fin = l;
-                } else cur = stack[--sp][lane];
+                } else if (went == PT_WIDE_NONE) cur = stack[--sp][lane];
             }
         }
         if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
@@ -391,7 +385,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     uint32_t steps = 0;
     float term0 = 0.f, term1 = 0.f, term2 = 0.f, term3 = 0.f;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayInv ray = make_ray_inv(o, d);
+    RayGrid ray = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}; // idle lanes: never used
     // where the lights x < y of the reference order separate in the reference's light tree (SceneView6::light_sep, see p6_merge_hits)
     auto sep = [&](uint32_t x, uint32_t y) {
         const uint32_t lv = 31u - (uint32_t)__clz((int)(y - x));
@@ -459,7 +453,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     const float4 *r = p6_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1], q4 = r[4];
                     o = f3(q4.x, q4.y, q4.z); d = f3(q0.w, q1.x, q1.y);                        // the pdf's ray: x + eps*n towards the sampled direction
-                    ray = make_ray_inv(o, d);
+                    ray = make_ray_grid(S.grid, o, d);
                     steps = 0;
                     cur = 0; sp = 0; k = 0; many = false; fragile = false; term0 = 0.f; term1 = 0.f;
                     active = true;
@@ -473,19 +467,14 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (inner) {
-                const float4 *q = reinterpret_cast<const float4 *>(S.fast_light_nodes + cur);
-                float4 lo0 = q[0], hi0 = q[1], lo1 = q[2], hi1 = q[3];
                 if (COUNT) n_nodes++;
                 steps++;
-                float n0, n1;
-                bool h0 = slab_test(lo0, hi0, ray, RT_T_MAX, n0);
-                bool h1 = slab_test(lo1, hi1, ray, RT_T_MAX, n1);
-                uint32_t c0 = __float_as_uint(lo0.w), c1 = __float_as_uint(lo1.w);
-                if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; }
-                else if (h0) cur = c0;
-                else if (h1) cur = c1;
-                else if (sp == 0) finish();
-                else cur = stack[--sp][lane];
+                const int went = pt_wide_step_all(S.fast_light_nodes4, ray, stack, lane, sp, P6_STACK, cur);
+                if (went == PT_WIDE_FULL) { many = true; fragile = false; k = RT6_MAX_LIGHT_HITS + 1; finish(); } // the slow role walks the sum in the reference's order
+                else if (went == PT_WIDE_NONE) {
+                    if (sp == 0) finish();
+                    else cur = stack[--sp][lane];
+                }
             }
         }
         if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves

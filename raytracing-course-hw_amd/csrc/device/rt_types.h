@@ -18,6 +18,17 @@ struct GpuNode {
 };
 static_assert(sizeof(GpuNode) == 64, "GpuNode must be 64 bytes");
 
+// Walk node of the persistent pipeline: the children of a GpuNode's two children (a child that is a leaf stays as it is), each as one
+// 16-byte record {x, y, z, child}: two levels of the tree per fetch of one 64-byte line — half the dependent node fetches of a walk.
+// The boxes lie on a 16-bit grid over the scene (NodeGrid), rounded outwards and one more cell: x = lo | hi << 16 along x, and so on.
+// The walkers move the ray into grid coordinates once per walk; a box of the grid contains the float box whatever that arithmetic
+// rounds (rt_device.h slab_test_q).  Unused records: child = 0xFFFFFFFF, a point in the grid's border.
+struct GpuNode4Q { uint32_t rec[4][4]; };
+static_assert(sizeof(GpuNode4Q) == 64, "GpuNode4Q must be 64 bytes");
+#define RT_GRID_CELLS 65000.0   // cells across the larger of: the axis' own extent, 1/64 of the largest extent
+#define RT_GRID_BORDER 4        // cells in front of the lowest box
+struct NodeGrid { float lo[3], step[3], istep[3]; };
+
 // Per-triangle intersection record, in the reference's BVH (figure) order.  All derived values are
 // computed on the host with the reference's float expressions (hw8/src/primitives.cpp:85-104), so
 // the kernel's test is bit-identical to Figure::intersectAsTriangle while fetching only 48 bytes.
@@ -90,6 +101,8 @@ struct SceneView {
     // records in ITS leaf order, pad = light index (position in `lights`) << 1 | last-of-leaf.  == light_nodes / lights with pads rewritten when the
     // scene has too few lights to bother (then the index is the position).
     const GpuNode *light_walk_nodes;
+    const GpuNode4Q *nodes4, *light_walk_nodes4;  // `nodes` / `light_walk_nodes` four wide on the 16-bit grid: what the persistent pipeline's walkers read
+    NodeGrid grid;                 // covers both trees' root boxes and the camera (every ray origin lies inside it)
     const LightRec *lights_walk;
     const uint16_t *light_sep;     // range-minimum table of the separation depths of neighbouring lights (scene_prep.h)
     const GpuMaterial *materials;

@@ -27,6 +27,8 @@ struct SceneView6 {
     const GpuNode *light_nodes;  // reference topology over the light list
     const Tri6 *lights;          // in the reference's light order
     const GpuNode *fast_light_nodes; // own SAH tree over the same lights: finds the hit lights quickly (order-free for <= 2 hits)
+    const GpuNode4Q *nodes4, *fast_light_nodes4; // `nodes` / `fast_light_nodes` four wide on the 16-bit grid (rt_types.h): what the persistent pipeline's walkers read
+    NodeGrid grid;                   // covers both trees' root boxes and the camera
     const Tri6 *fast_lights;         // the light records in that tree's leaf order (ref_index = position in the reference's light order)
     const uint32_t *light_ref;       // the reference light tree without boxes: 4 words {left, right, first, last} per node (left = 0: leaf)
     const uint16_t *light_sep;       // range-minimum table of the separation depths of neighbouring lights in the reference light tree (scene_prep.h)

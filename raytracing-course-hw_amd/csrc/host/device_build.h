@@ -24,4 +24,12 @@ void free_device_tree(DeviceTree &t);
 // 1 / 0 (last slot of its leaf or not), or, with or_into_word, keeps its value and gets the mark in bit 0 (mark_word_offset < 0: no marks).
 void gather_records(const void *d_in, void *d_out, const DeviceTree &t, uint32_t n, uint32_t elem_bytes, int mark_word_offset, bool or_into_word = false);
 
+// The persistent pipeline's walk nodes on their 16-bit grid (rt_types.h GpuNode4Q, device/rt_node_grid.h):
+// The union of the two child boxes of d_nodes[0] (empty children skipped) joins lo / hi.  Synchronous.
+void join_root_box(const GpuNode *d_nodes, float lo[3], float hi[3]);
+
+// The tree d_nodes[0, n) with two levels folded into each node (rt_types.h GpuNode4Q), on the grid; hipMalloc'ed.  depth_out: levels of
+// the wide tree (at most half the two-box tree's, rounded up).  Synchronous (the fold runs on the host).  Throws when a box does not fit.
+GpuNode4Q *widen_nodes(const GpuNode *d_nodes, uint32_t n, const NodeGrid &grid, uint32_t &n_out, uint32_t &depth_out);
+
 } // namespace rtamd

@@ -17,6 +17,7 @@
 #include "host/scene_prep.h"
 #include "host/shared_prep.h"
 #include "host/hip_check.h"
+#include "device/rt_node_grid.h"
 #include "host/device_build.h"
 #include "device/rt_kernels_hw8.h"
 #include "device/rt_wavefront.h"
@@ -79,6 +80,7 @@ struct rt_scene {
     int flavor = RT_INTEGRATOR_HW8; // which integrator this scene was prepared for
     bool hw6_lds_stack = false, hw6_pt_stack = false;
     uint32_t light_walk_depth = 0;   // hw8: depth of the tree the persistent kernel's light walker uses
+    uint32_t wide_depth = 0, wide_light_depth = 0; // levels of the four-wide forms of the two walk trees (rt_types.h GpuNode4Q)
     std::vector<void *> allocations;
     rt_scene_info info{};
     std::vector<uint32_t> light_order;
@@ -303,6 +305,18 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
             V.tan_fov_y = (float)std::tan((double)(desc->camera.fov_y / 2));
             s->view.tan_fov_y = V.tan_fov_y;
             s->flavor = RT_INTEGRATOR_HW6;
+            {   // the walk nodes of the persistent pipeline (rt_types.h GpuNode4Q), as for hw8
+                float glo[3], ghi[3];
+                for (int k = 0; k < 3; k++) glo[k] = ghi[k] = V.cam_pos[k];
+                join_root_box(V.nodes, glo, ghi);
+                join_root_box(V.fast_light_nodes, glo, ghi);
+                V.grid = make_node_grid(glo, ghi);
+                uint32_t n4 = 0, n4l = 0, d4 = 0, d4l = 0;
+                V.nodes4 = keep(widen_nodes(V.nodes, (uint32_t)P6.nodes.size(), V.grid, n4, d4));
+                V.fast_light_nodes4 = keep(widen_nodes(V.fast_light_nodes, (uint32_t)P6.fast_light_nodes.size(), V.grid, n4l, d4l));
+                bytes += ((uint64_t)n4 + n4l) * sizeof(GpuNode4Q);
+                s->wide_depth = d4; s->wide_light_depth = d4l;
+            }
             HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
             s->allocations.push_back(s->d_work_counter);
             HIP_CHECK(hipMalloc((void **)&s->d_counters, 512));
@@ -343,15 +357,18 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
         uint32_t ref_depth = P.bvh_depth;
         if (walk_tree_on_device) {
             const uint32_t n = desc->n_triangles;
+            // The persistent kernel's walkers take two levels per step (GpuNode4Q) and hold up to three entries per step in a stack column
+            // of P8_STACK entries; a walk that runs out of room is redone by the exact role with a stack of its own (rt_persistent.h).
+            const uint32_t walk_depth_cap = P8_STACK;
             DeviceTree t;
             TriIsect *d_walk = nullptr;
             try {
                 if (!P.walk_box.empty()) { // reference leaf boxes (scene_prep.h)
                     uint64_t scratch = 0;
                     float *d_walk_box = upload(P.walk_box, scratch);
-                    try { t = build_tree_on_device(d_walk_box, n, P.box_pad, P8_STACK); } catch (...) { (void)hipFree(d_walk_box); throw; }
+                    try { t = build_tree_on_device(d_walk_box, n, P.box_pad, walk_depth_cap); } catch (...) { (void)hipFree(d_walk_box); throw; }
                     (void)hipFree(d_walk_box);
-                } else t = build_tree_on_device(V.tri_box, n, P.box_pad, P8_STACK); // no deeper than the persistent kernel's stack columns
+                } else t = build_tree_on_device(V.tri_box, n, P.box_pad, walk_depth_cap);
                 HIP_CHECK(hipMalloc((void **)&d_walk, (size_t)n * sizeof(TriIsect)));
                 gather_records(V.tri_isect, d_walk, t, n, sizeof(TriIsect), 11, true); // word 11 = TriIsect::pad: figure index << 1 | leaf mark
                 HIP_CHECK(hipDeviceSynchronize());
@@ -387,6 +404,7 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
         V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || fast_build) ? 0u : 1u; // RT_BUILD_DEVICE_BVH: there is no reference tree to be exact about
         if (getenv("RTAMD_DIAG_LOOKBEHIND_ONLY")) V.exact_boxes = 2u; // diagnostic (timing only, pixels NOT exact): the walkers look behind as with the gate, every hit stands
         V.lights = keep(upload(P.lights, bytes));
+        uint32_t n_light_walk_nodes = 0;
         {   // the light walker's own tree (rt_types.h: light_walk_nodes / lights_walk)
             const uint32_t nl = (uint32_t)P.lights.size();
             std::vector<LightRec> tagged = P.lights; // pad = light index << 1 | last-of-leaf (of the REFERENCE topology for now)
@@ -413,8 +431,10 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
                 V.light_walk_nodes = keep(lt.nodes); V.lights_walk = keep(d_walk);
                 bytes += (uint64_t)lt.n_nodes * sizeof(GpuNode);
                 s->light_walk_depth = lt.depth;
+                n_light_walk_nodes = lt.n_nodes;
             } else {
                 V.light_walk_nodes = V.light_nodes;
+                n_light_walk_nodes = (uint32_t)P.light_nodes.size();
                 V.lights_walk = keep(upload(tagged, bytes));
                 s->light_walk_depth = P.light_bvh_depth;
             }
@@ -444,6 +464,18 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
         }
         s->fov_y = desc->camera.fov_y;
         V.tan_fov_y = (float)std::tan((double)(desc->camera.fov_y / 2)); // scene.cpp:180 (host libm, like the reference)
+        {   // the walk nodes of the persistent pipeline: both trees four wide on one 16-bit grid that also holds the camera (rt_types.h GpuNode4Q)
+            float glo[3], ghi[3];
+            for (int k = 0; k < 3; k++) glo[k] = ghi[k] = V.cam_pos[k];
+            join_root_box(V.nodes, glo, ghi);
+            if (n_light_walk_nodes) join_root_box(V.light_walk_nodes, glo, ghi);
+            V.grid = make_node_grid(glo, ghi);
+            uint32_t n4 = 0, n4l = 0, d4 = 0, d4l = 0;
+            V.nodes4 = keep(widen_nodes(V.nodes, n_nodes, V.grid, n4, d4));
+            V.light_walk_nodes4 = keep(widen_nodes(V.light_walk_nodes, n_light_walk_nodes, V.grid, n4l, d4l));
+            bytes += ((uint64_t)n4 + n4l) * sizeof(GpuNode4Q);
+            s->wide_depth = d4; s->wide_light_depth = d4l;
+        }
         HIP_CHECK(hipMalloc((void **)&s->d_work_counter, 64));
         s->allocations.push_back(s->d_work_counter);
         HIP_CHECK(hipMalloc((void **)&s->d_counters, 512));

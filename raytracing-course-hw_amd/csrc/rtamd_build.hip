@@ -1,7 +1,11 @@
 // Driver of the on-device scene-tree builder: device/rt_bvh_build.h has the kernels and the description of the algorithm.
 #include "device/rt_bvh_build.h"
+#include "device/rt_node_grid.h"
 #include "host/device_build.h"
 #include "host/hip_check.h"
+#include <cmath>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace rtamd {
@@ -20,6 +24,62 @@ __global__ void gather16_kernel(const float4 *in, float4 *out, const uint32_t *o
     }
 }
 } // namespace
+
+void join_root_box(const GpuNode *d_nodes, float lo[3], float hi[3]) {
+    GpuNode root;
+    HIP_CHECK(hipMemcpy(&root, d_nodes, sizeof root, hipMemcpyDeviceToHost));
+    auto join = [&](const float *l, const float *h) { for (int k = 0; k < 3; k++) { if (l[k] < lo[k]) lo[k] = l[k]; if (h[k] > hi[k]) hi[k] = h[k]; } };
+    if ((uint32_t)root.child0 != 0xFFFFFFFFu) join(root.lo0, root.hi0);
+    if ((uint32_t)root.child1 != 0xFFFFFFFFu) join(root.lo1, root.hi1);
+}
+
+GpuNode4Q *widen_nodes(const GpuNode *d_nodes, uint32_t n, const NodeGrid &grid, uint32_t &n_out, uint32_t &depth_out) {
+    std::vector<GpuNode> nodes(n ? n : 1);
+    if (n) HIP_CHECK(hipMemcpy(nodes.data(), d_nodes, (size_t)n * sizeof(GpuNode), hipMemcpyDeviceToHost));
+    else { GpuNode e{}; e.child0 = e.child1 = (int32_t)0xFFFFFFFFu; nodes[0] = e; }
+    struct Entry { const float *lo, *hi; uint32_t child; };
+    std::vector<GpuNode4Q> wide;
+    std::vector<uint32_t> source{0u}, level{1u}; // wide node -> the two-box node it folds, its level
+    wide.reserve(nodes.size() / 2 + 1);
+    uint32_t misfits = 0;
+    depth_out = 1;
+    for (size_t w = 0; w < source.size(); w++) {
+        const GpuNode &b = nodes[source[w]];
+        Entry e[4]; int ne = 0;
+        auto take = [&](const float *lo, const float *hi, uint32_t child) {
+            if (child == 0xFFFFFFFFu) return;                       // empty
+            if (child & 0x80000000u) { e[ne++] = Entry{lo, hi, child}; return; } // leaf: stays
+            if (child >= nodes.size()) throw std::runtime_error("widen_nodes: child index out of range");
+            const GpuNode &c = nodes[child];                         // inner: its two children take its place
+            const uint32_t cc[2] = {(uint32_t)c.child0, (uint32_t)c.child1};
+            const float *clo[2] = {c.lo0, c.lo1}, *chi[2] = {c.hi0, c.hi1};
+            for (int k = 0; k < 2; k++) if (cc[k] != 0xFFFFFFFFu) e[ne++] = Entry{clo[k], chi[k], cc[k]};
+        };
+        take(b.lo0, b.hi0, (uint32_t)b.child0);
+        take(b.lo1, b.hi1, (uint32_t)b.child1);
+        GpuNode4Q q;
+        for (int k = 0; k < 4; k++) {
+            if (k >= ne) { q.rec[k][0] = q.rec[k][1] = q.rec[k][2] = 0u; q.rec[k][3] = 0xFFFFFFFFu; continue; } // a point in the grid's border
+            bool fits = true;
+            for (int a = 0; a < 3; a++) q.rec[k][a] = grid_axis_word(e[k].lo[a], e[k].hi[a], grid.lo[a], grid.step[a], fits);
+            if (!fits) misfits++;
+            uint32_t child = e[k].child;
+            if (!(child & 0x80000000u)) { // inner: gets the next wide node
+                source.push_back(child); level.push_back(level[w] + 1);
+                if (level[w] + 1 > depth_out) depth_out = level[w] + 1;
+                child = (uint32_t)(source.size() - 1);
+            }
+            q.rec[k][3] = child;
+        }
+        wide.push_back(q);
+    }
+    if (misfits) throw std::runtime_error("widen_nodes: " + std::to_string(misfits) + " node boxes do not fit the scene's grid");
+    n_out = (uint32_t)wide.size();
+    GpuNode4Q *out = nullptr;
+    HIP_CHECK(hipMalloc((void **)&out, wide.size() * sizeof(GpuNode4Q)));
+    if (hipMemcpy(out, wide.data(), wide.size() * sizeof(GpuNode4Q), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(out); throw std::runtime_error("widen_nodes: upload failed"); }
+    return out;
+}
 
 DeviceTree build_tree_on_device(const float *d_boxes, uint32_t n, float abs_pad, uint32_t max_depth) {
     DeviceTree t;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "device/rt_device.h"
 #include "device/rt_exact.h"
+#include "device/rt_node_grid.h"
 
 using namespace rtamd::dev;
 
@@ -35,7 +36,38 @@ __global__ void k_stands(const float *in, uint32_t *out, size_t n) { // per case
     out[i] = pt_hit_stands(f3(p[0], p[1], p[2]), f3(p[3], p[4], p[5]), f3(p[6], p[7], p[8]), f3(p[9], p[10], p[11]), p[12], p[13], p[14], 1.25f * p[14], p[15]) ? 1u : 0u;
 }
 
+// rt_device.h slab_test_q against slab_test: a box on the walkers' 16-bit grid must be entered by every ray that enters the float box
+__global__ void k_slab_q(const float *in, rtamd::NodeGrid G, uint32_t *out, size_t n) { // per case 13 floats: lo.xyz hi.xyz o.xyz d.xyz tbest
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = in + 13 * i;
+    const F3 o = f3(p[6], p[7], p[8]), d = f3(p[9], p[10], p[11]);
+    float tn = 0.f, tq = 0.f;
+    const bool hf = slab_test(make_float4(p[0], p[1], p[2], 0.f), make_float4(p[3], p[4], p[5], 0.f), make_ray_inv(o, d), p[12], tn);
+    bool fits = true;
+    uint4 b;
+    b.x = rtamd::grid_axis_word(p[0], p[3], G.lo[0], G.step[0], fits);
+    b.y = rtamd::grid_axis_word(p[1], p[4], G.lo[1], G.step[1], fits);
+    b.z = rtamd::grid_axis_word(p[2], p[5], G.lo[2], G.step[2], fits);
+    b.w = 0u;
+    const bool hq = slab_test_q(b, make_ray_grid(G, o, d), p[12], tq);
+    out[i] = (hf ? 1u : 0u) | (hq ? 2u : 0u) | (fits ? 4u : 0u) | (tq <= tn ? 8u : 0u);
+}
+
 extern "C" {
+// grid_box: lo.xyz hi.xyz of what the grid must hold.  out bits: 1 float box entered, 2 grid box entered, 4 the box fits the grid, 8 grid entry <= float entry
+int rtt_slab_q(const float *cases, const float *grid_box, uint32_t *out, size_t n) {
+    const rtamd::NodeGrid G = rtamd::make_node_grid(grid_box, grid_box + 3);
+    float *d_in = nullptr; uint32_t *d_out = nullptr;
+    if (hipMalloc((void **)&d_in, n * 13 * 4) != hipSuccess || hipMalloc((void **)&d_out, n * 4) != hipSuccess) return -1;
+    int rc = -1;
+    if (hipMemcpy(d_in, cases, n * 13 * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(k_slab_q, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, G, d_out, n);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
+}
 int rtt_gap_code(const float *t, const float *t2, float *floor_out, uint32_t *code_out, size_t n) {
     float *d_t = nullptr, *d_t2 = nullptr, *d_f = nullptr; uint32_t *d_c = nullptr;
     if (hipMalloc((void **)&d_t, n * 4) != hipSuccess || hipMalloc((void **)&d_t2, n * 4) != hipSuccess || hipMalloc((void **)&d_f, n * 4) != hipSuccess || hipMalloc((void **)&d_c, n * 4) != hipSuccess) return -1;

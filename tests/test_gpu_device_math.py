@@ -97,3 +97,53 @@ def test_gate_decisions_on_constructed_cases(hooks):
     assert hooks.rtt_hit_stands(cases.ctypes.data, out.ctypes.data, len(cases)) == 0
     print("gate decisions:", out.tolist())
     assert out.tolist() == [1, 0, 0, 1, 0, 1, 0, 0]
+
+
+def test_grid_boxes_are_entered_by_every_ray_that_enters_the_float_box(hooks):
+    """The persistent pipeline's walkers read their node boxes from a 16-bit grid over the scene (rt_types.h GpuNodeQ,
+    device/rt_node_grid.h) and test them with the ray moved into grid coordinates (rt_device.h slab_test_q).  Pruning must stay
+    conservative: whenever the float test (slab_test, what every other pipeline walks with) enters a box, the grid test enters it
+    too — for origins anywhere in the grid's box (camera corner included), rays along the axes, flat boxes, origins on box
+    faces, thin scenes."""
+    rng = np.random.default_rng(11)
+    hooks.rtt_slab_q.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    total_hits = 0
+    for scene_lo, scene_hi in (((-10.0, -3.0, -10.0), (10.0, 5.0, 10.0)),        # a room
+                               ((100.0, 100.0, -0.001), (100.5, 130.0, 0.001)),     # far from the origin, thin along z
+                               ((-1e-3, -1e-3, -1e-3), (1e-3, 1e-3, 1e-3)),         # tiny
+                               ((0.0, 0.0, 0.0), (4000.0, 1.0, 0.0))):              # flat along z, long along x
+        lo_s, hi_s = np.array(scene_lo), np.array(scene_hi)
+        n = 400_000
+        ext = hi_s - lo_s
+        c = rng.uniform(lo_s, hi_s, (n, 3))
+        half = rng.uniform(0, 1, (n, 3)) ** 4 * 0.25 * ext * rng.choice([0.0, 1.0, 1.0, 1.0], (n, 3))  # some flat boxes
+        blo = np.maximum(c - half, lo_s).astype(np.float32)
+        bhi = np.minimum(c + half, hi_s).astype(np.float32)
+        bhi = np.maximum(bhi, blo)
+        o = rng.uniform(lo_s, hi_s, (n, 3))
+        o[: n // 8] = lo_s                                                        # the grid's own corner: the largest grid coordinates are at the other end
+        o[n // 8: n // 4] = hi_s
+        face = rng.integers(0, 3, n)
+        on_face = rng.random(n) < 0.2                                             # origins on a face of their box
+        o[on_face, face[on_face]] = blo[on_face, face[on_face]]
+        target = rng.uniform(blo, np.maximum(bhi, blo))                           # aim at the box, so that most rays matter
+        d = target - o + rng.normal(0, 1e-3, (n, 3)) * ext                     # noise per axis: thin scenes keep their hits
+        axis_par = rng.random(n) < 0.15                                           # rays along an axis: a zero component
+        d[axis_par, face[axis_par]] = 0.0
+        nz = np.linalg.norm(d, axis=1) > 0
+        d[~nz] = (1.0, 0.0, 0.0)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        tbest = np.where(rng.random(n) < 0.5, 3.0e38, rng.uniform(0, 2, n) * np.linalg.norm(ext)).astype(np.float32)
+        cases = np.concatenate([blo, bhi, o.astype(np.float32), d.astype(np.float32), tbest[:, None]], axis=1).astype(np.float32)
+        cases = np.ascontiguousarray(cases)
+        grid_box = np.concatenate([lo_s, hi_s]).astype(np.float32)
+        out = np.zeros(n, np.uint32)
+        assert hooks.rtt_slab_q(cases.ctypes.data, grid_box.ctypes.data, out.ctypes.data, n) == 0
+        fits = (out & 4) != 0
+        hit_f, hit_q = (out & 1) != 0, (out & 2) != 0
+        lost = hit_f & ~hit_q
+        total_hits += int(hit_f.sum())
+        print(f"grid over {scene_lo}..{scene_hi}: {int(hit_f.sum())} float hits, {int(hit_q.sum())} grid hits, {int(lost.sum())} lost, {int((~fits).sum())} misfits")
+        assert fits.all()
+        assert not lost.any(), cases[lost][:5]
+    assert total_hits > 300_000     # the cases do exercise the test

@@ -185,8 +185,16 @@ def test_full_config_1920x1080x256_crops_match_oracle(rt, tmp_path):
         os.environ.pop("RTAMD_ROUNDS_EXACT", None)
     print(f"full frame: pipeline {st_b.pipeline}, {st_b.kernel_ms:.1f} ms kernel = {1920 * 1080 * 256 / st_b.kernel_ms / 1e3:.1f} Msamples/s")
     assert {st.pipeline, st_b.pipeline} == {rt.RT_PIPELINE_PERSISTENT, rt.RT_PIPELINE_ROUNDS}
-    assert np.array_equal(rgb, rgb_b) and np.array_equal(rgb8, rgb8_b)
     orc = oracle_lib.Hw8Oracle(sd)
+    # The two organisations walk different boxes (the persistent pipeline: the 16-bit grid nodes, a superset of the round pipeline's
+    # padded float boxes), so they can differ where the reference's triangle test reports a hit outside the triangle's padded box and
+    # only the wider boxes lead the walk to it (1 pixel of the frame in round 3, by one ulp).  The default pipeline must be the right one.
+    differ = np.argwhere(np.any(rgb != rgb_b, axis=2))
+    print(f"{len(differ)} pixels differ between the two organisations")
+    assert len(differ) <= 4
+    for (y, x) in differ:
+        ref, _, _ = orc.render(1920, 1080, 256, rect=(int(x), int(y), 1, 1))
+        assert np.array_equal(rgb[y, x], ref.reshape(-1, 3)[0]), f"pixel ({x},{y}): the persistent pipeline differs from the oracle"
     worst = 0.0
     # 100 crops: the eight of round 1, tile (192,192) — the worst tile of round 1's 300-tile sweep, where the padded box test of the
     # round pipeline kept a hit the reference's slab test drops — 27 more on a jittered lattice

@@ -82,6 +82,14 @@ namespace dev {
 #ifndef PT_QUANT_NODES
 #define PT_QUANT_NODES 1       // the walkers read the four-wide grid nodes (rt_types.h GpuNode4Q: two levels per fetch); 0 = the two-box float nodes, for A/B builds
 #endif
+#ifndef PT_POSTPONE
+#define PT_POSTPONE 1          // walkers keep a leaf they meet for the next leaf phase and walk on (0: they wait at it), for A/B builds
+#endif
+#if !PT_QUANT_NODES
+#undef PT_POSTPONE
+#define PT_POSTPONE 0          // the two-box float path keeps the plain loop
+#endif
+#define PT_DRAINED 0xFFFFFFFEu        // `cur` of a lane whose stack is empty and whose last leaf is still to be tested (reads as a leaf: the lane waits)
 #define PT_T_OVERFLOW (-1.f)          // t of a closest-hit record whose walk ran out of stack: the exact role redoes the query
 // ---- one step of a walk over the four-wide grid nodes (rt_types.h GpuNode4Q), shared with rt_persistent_hw6.h ------------------------
 #define PT_WIDE_NONE 0                // no child entered: the caller pops its stack
@@ -179,7 +187,7 @@ struct PtParams {
     const uint32_t *group_ofs, *group_ids;
     uint32_t *group_cost;
     uint32_t resume;
-    int refill, leaf_batch;           // as in rt_wavefront.h (leaf_batch = batch | share << 16)
+    int refill, leaf_batch;           // as in rt_wavefront.h (refill = closest-hit walker's | light walker's << 16; leaf_batch = batch | share << 16)
     int shade_min;                    // a wave turns shader when this many paths wait for shading (64 = a full wave of them)
     int shade_thr0, shade_thr_step;   // wave w stops refilling its walkers when need_shade holds >= thr0 + w * step paths
     int cost_t, cost_l;               // relative cost of a closest-hit / light query (walker split)
@@ -197,6 +205,14 @@ struct PtParams {
 struct PtProf {
     unsigned long long t_trace = 0, t_light = 0, t_shade = 0, t_exact = 0, t_idle = 0;
     unsigned long long trace_iters = 0, trace_lane_iters = 0, light_iters = 0, light_lane_iters = 0, stints = 0, shade_batches = 0, shade_items = 0;
+    // where a walker's wave time goes (counting build): [0] hand-off and refill, [1] inner nodes, [2] leaves; tests / lane-tests of the leaf loops; light hits
+    unsigned long long t_part[2][3] = {{0, 0, 0}, {0, 0, 0}}, leaf_iters[2] = {0, 0}, leaf_lane_iters[2] = {0, 0}, light_hits = 0, light_tests = 0; // the last two per lane
+    unsigned long long t_sub[2][3] = {{0, 0, 0}, {0, 0, 0}}, refills[2] = {0, 0}; // of [0]: publish finished walks | take new ones from the bitmap | read their rays
+};
+template <bool COUNT> struct PtLap { // s_memtime laps of the counting build
+    unsigned long long t;
+    RT_DEV PtLap() : t(COUNT ? __builtin_amdgcn_s_memtime() : 0ull) {}
+    RT_DEV void lap(unsigned long long &acc) { if (COUNT) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc += n - t; t = n; } }
 };
 
 // wave-uniform state
@@ -305,6 +321,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     bool active = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
     int sp = 0;
+    uint32_t pend = RT_EMPTY_LEAF; (void)pend; // PT_POSTPONE: the leaf this lane has met and not yet tested
     uint32_t steps = 0;   // node steps + triangle tests of the lane's current walk: the cost measure of the re-deal (PT_COST_*)
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     PtRay ray = PT_RAY_IDLE; // idle lanes: never used
@@ -316,21 +333,26 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         wf_rec(W, slot)[2] = make_float4(best_t, best_u, best_v, __uint_as_float(S.exact_boxes && hit != WF_MISS ? hit | pt_gap_code(best_t, t2) : hit));
         if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps);
     };
+    PtLap<COUNT> clk;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
-        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+        if (idle && (__popcll(idle) >= (P.refill & 0xFFFF) || idle == ~0ull)) {
             // Hand-off point.  Finished lanes are published here and not the moment they finish: the release (a wait for the
             // wave's outstanding record stores) is paid once per refill, when the stores have long landed, not once per walk.
+            PtLap<COUNT> sub;
+            if (COUNT) prof.refills[0]++;
             if (__ballot(fin != PT_NONE)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
                 fin = PT_NONE;
             }
+            sub.lap(prof.t_sub[0][0]);
             if (!refill_ok) {}
             else if (pt_count(&sh.cnt[PT_Q_SHADE]) >= shade_thr) refill_ok = false;      // shaders are behind: drain, then help them
             else if (pt_count(&sh.cnt[PT_Q_TRACE]) > 0) {
                 const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                sub.lap(prof.t_sub[0][1]);
                 n_queries += __popcll(__ballot(got != PT_NONE));
                 if (got != PT_NONE) {
                     l = got; slot = pt_slot(sh, l);
@@ -340,15 +362,26 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     ray = pt_make_ray(S, o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     steps = 0;
-                    cur = 0; sp = 0; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                     active = true;
                 }
+                if (COUNT) { asm volatile("" : "+v"(ray.ix)); sub.lap(prof.t_sub[0][2]); }
             }
         }
         const unsigned long long m_active = __ballot(active);
+        clk.lap(prof.t_part[0][0]);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes
+#if PT_POSTPONE
+            // A lane that meets a leaf keeps it for the next leaf phase and walks on with what its stack holds (a second leaf stops it):
+            // more lanes stay in the node loop, and more of them bring a leaf to each leaf phase.
+            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) {
+                pend = cur;
+                cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
+                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) { store_hit(); active = false; fin = l; } // an empty leaf was all that was left
+            }
+#endif
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) { prof.trace_iters++; prof.trace_lane_iters += __popcll(__ballot(inner)); }
@@ -358,14 +391,20 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #if PT_QUANT_NODES
                 const int went = pt_wide_step_nearest(S.nodes4, ray, cull_t, stack, lane, sp, P8_STACK, cur);
                 if (went == PT_WIDE_NONE) {
+#if PT_POSTPONE
+                    if (sp != 0) cur = stack[--sp][lane];
+                    else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
+                    else { store_hit(); active = false; fin = l; }
+#else
                     if (sp == 0) { store_hit(); active = false; fin = l; }
                     else cur = stack[--sp][lane];
+#endif
                 } else if (went == PT_WIDE_FULL) {
                     // The column is full (a walk holds up to three entries per level of a tree of up to P8_STACK / 2 levels; this takes a
                     // ray that grazes many boxes: triangle soups).  The walk ends here and says so — no hit has a negative t — and the
                     // exact role walks the query with a stack of its own (pt_exact_batch).
                     best_t = PT_T_OVERFLOW; best_u = 0.f; best_v = 0.f; hit = 0u; t2 = PT_T_OVERFLOW;
-                    store_hit(); active = false; fin = l;
+                    store_hit(); active = false; fin = l; pend = RT_EMPTY_LEAF;
                 }
 #else
                 float n0, n1;
@@ -387,9 +426,18 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #endif
             }
         }
-        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
-            if (cur != RT_EMPTY_LEAF) {
-                uint32_t i = cur & ~RT_LEAF_BIT;
+        clk.lap(prof.t_part[0][1]);
+#if PT_POSTPONE
+        const bool at_leaf = active && pend != RT_EMPTY_LEAF;
+        const uint32_t leaf = pend;
+#else
+        const bool at_leaf = active && (cur & RT_LEAF_BIT);
+        const uint32_t leaf = cur;
+#endif
+        if (COUNT) { prof.leaf_iters[0]++; prof.leaf_lane_iters[0] += __popcll(__ballot(at_leaf)); }
+        if (at_leaf) { // phase 2: leaves
+            if (leaf != RT_EMPTY_LEAF) {
+                uint32_t i = leaf & ~RT_LEAF_BIT;
                 for (;;) {
                     TriIsect T = load_isect(S.tri_walk + i);
                     if (COUNT) n_tris++;
@@ -408,11 +456,17 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     i++;
                 }
             }
+#if PT_POSTPONE
+            pend = RT_EMPTY_LEAF;
+            if (cur == PT_DRAINED) { store_hit(); active = false; fin = l; } // a lane that stopped at a second leaf keeps that for the next round
+#else
             if (sp == 0) {
                 store_hit();
                 active = false; fin = l;
             } else cur = stack[--sp][lane];
+#endif
         }
+        clk.lap(prof.t_part[0][2]);
     }
 }
 
@@ -424,6 +478,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     bool active = false, overflow = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE; // fin: the lane's finished, unpublished path; bit 31 = it needs the exact role instead
     int sp = 0, k = 0;
+    uint32_t pend = RT_EMPTY_LEAF; (void)pend; // PT_POSTPONE: the leaf this lane has met and not yet tested
     uint32_t steps = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     PtRay ray = PT_RAY_IDLE; // idle lanes: never used
@@ -461,9 +516,10 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         *pdf = *pdf + v / S.n_lights_f;                                  // distributions.h:123,273
         fin = l;
     };
+    PtLap<COUNT> clk;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
-        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+        if (idle && (__popcll(idle) >= (P.refill >> 16) || idle == ~0ull)) {
             if (__ballot(fin != PT_NONE)) { // hand-off point, see pt_trace_stint
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 const bool slow = (fin >> 31) != 0u && fin != PT_NONE;
@@ -483,15 +539,23 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = pt_make_ray(S, o, d);
-                    cur = 0; sp = 0; k = 0; overflow = false; steps = 0;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; k = 0; overflow = false; steps = 0;
                     active = true;
                 }
             }
         }
         const unsigned long long m_active = __ballot(active);
+        clk.lap(prof.t_part[1][0]);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes
+#if PT_POSTPONE
+            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) { // the leaf waits for the next leaf phase (pt_trace_stint)
+                pend = cur;
+                cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
+                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) finish();
+            }
+#endif
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (COUNT) { prof.light_iters++; prof.light_lane_iters += __popcll(__ballot(inner)); }
@@ -501,9 +565,15 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #if PT_QUANT_NODES
                 const int went = pt_wide_step_all(S.light_walk_nodes4, ray, stack, lane, sp, P8_STACK - 2 * k - 1, cur); // the hits sit at the column's top
                 if (went == PT_WIDE_NONE) {
+#if PT_POSTPONE
+                    if (sp != 0) cur = stack[--sp][lane];
+                    else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
+                    else finish();
+#else
                     if (sp == 0) finish();
                     else cur = stack[--sp][lane];
-                } else if (went == PT_WIDE_FULL) { overflow = true; finish(); } // no room beside the hits: the slow role sums this query
+#endif
+                } else if (went == PT_WIDE_FULL) { overflow = true; pend = RT_EMPTY_LEAF; finish(); } // no room beside the hits: the slow role sums this query
 #else
                 float n0, n1;
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_walk_nodes + cur);
@@ -519,14 +589,24 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #endif
             }
         }
-        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
-            if (cur != RT_EMPTY_LEAF) {
-                uint32_t i = cur & ~RT_LEAF_BIT;
+        clk.lap(prof.t_part[1][1]);
+#if PT_POSTPONE
+        const bool at_leaf = active && pend != RT_EMPTY_LEAF;
+        const uint32_t leaf = pend;
+#else
+        const bool at_leaf = active && (cur & RT_LEAF_BIT);
+        const uint32_t leaf = cur;
+#endif
+        if (COUNT) { prof.leaf_iters[1]++; prof.leaf_lane_iters[1] += __popcll(__ballot(at_leaf)); }
+        if (at_leaf) { // phase 2: leaves
+            if (leaf != RT_EMPTY_LEAF) {
+                uint32_t i = leaf & ~RT_LEAF_BIT;
                 for (;;) {
                     bool last, robust; uint32_t li;
-                    if (COUNT) n_tris++;
+                    if (COUNT) { n_tris++; prof.light_tests++; }
                     steps += PT_COST_LIGHT_TEST;
                     float term = pt_light_pdf_one(S, S.lights_walk + i, o, d, last, robust, li);
+                    if (COUNT && term != 0.f) prof.light_hits++;
                     if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
                         if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= P8_STACK) overflow = true;
                         else { // kept sorted by light index (this tree's leaf order is not the light order): hit j at words P8_STACK-1-2j (index), -2-2j (term)
@@ -543,9 +623,15 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     i++;
                 }
             }
+#if PT_POSTPONE
+            pend = RT_EMPTY_LEAF;
+            if (cur == PT_DRAINED) finish();
+#else
             if (sp == 0) finish();
             else cur = stack[--sp][lane];
+#endif
         }
+        clk.lap(prof.t_part[1][2]);
     }
 }
 
@@ -927,12 +1013,19 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
     }
     if (COUNT && P.counters) {
         atomicAdd(&P.counters[2], n_nodes); atomicAdd(&P.counters[3], n_tris);
-        if (lane == 0) { // wave-level profile, words 16..27
+        atomicAdd(&P.counters[58], prof.light_hits); atomicAdd(&P.counters[59], prof.light_tests);
+        if (lane == 0) { // wave-level profile, words 16..27 and 48..57
             atomicAdd(&P.counters[16], prof.t_trace); atomicAdd(&P.counters[17], prof.t_light); atomicAdd(&P.counters[18], prof.t_shade);
             atomicAdd(&P.counters[19], prof.t_exact); atomicAdd(&P.counters[20], prof.t_idle);
             atomicAdd(&P.counters[21], prof.trace_iters); atomicAdd(&P.counters[22], prof.trace_lane_iters);
             atomicAdd(&P.counters[23], prof.light_iters); atomicAdd(&P.counters[24], prof.light_lane_iters);
             atomicAdd(&P.counters[25], prof.stints); atomicAdd(&P.counters[26], prof.shade_batches); atomicAdd(&P.counters[27], prof.shade_items);
+            for (int k = 0; k < 3; k++) atomicAdd(&P.counters[60 + k], prof.t_sub[0][k]);
+            atomicAdd(&P.counters[63], prof.refills[0]);
+            for (int w = 0; w < 2; w++) {
+                for (int k = 0; k < 3; k++) atomicAdd(&P.counters[48 + 3 * w + k], prof.t_part[w][k]);
+                atomicAdd(&P.counters[54 + 2 * w], prof.leaf_iters[w]); atomicAdd(&P.counters[55 + 2 * w], prof.leaf_lane_iters[w]);
+            }
         }
     }
     if (P.debug && lane == 0) {

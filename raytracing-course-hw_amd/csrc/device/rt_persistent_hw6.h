@@ -296,12 +296,13 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     bool best_inside = false;
     int sp = 0;
     uint32_t steps = 0; // node steps + triangle tests of the lane's walk: the cost measure of the re-deal
+    uint32_t pend = RT_EMPTY_LEAF; // the leaf this lane has met and not yet tested
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayGrid ray = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}; // idle lanes: never used
     float best_t = RT_T_MAX, cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // look-behind and runner-up: rt_exact.h
     for (;;) {
         const unsigned long long idle = __ballot(!active);
-        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+        if (idle && (__popcll(idle) >= (P.refill & 0xFFFF) || idle == ~0ull)) {
             if (__ballot(fin != PT_NONE)) { // hand-off point (rt_persistent.h)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
@@ -321,7 +322,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     ray = make_ray_grid(S.grid, o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     steps = 0;
-                    cur = 0; sp = 0; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
                     active = true;
                 }
             }
@@ -329,24 +330,34 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         const unsigned long long m_active = __ballot(active);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
-        for (;;) { // phase 1: inner nodes
+        auto done = [&]() {
+            p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
+            if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_TRACE_STEP);
+            active = false; fin = l;
+        };
+        for (;;) { // phase 1: inner nodes; a leaf waits in `pend` for the next leaf phase while the lane walks on (rt_persistent.h, pt_trace_stint)
+            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) {
+                pend = cur;
+                cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
+                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) done();
+            }
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (inner) {
                 if (COUNT) n_nodes++;
                 steps++;
                 const int went = pt_wide_step_nearest(S.nodes4, ray, cull_t, stack, lane, sp, P6_STACK, cur);
-                if (went == PT_WIDE_FULL) { best_t = PT_T_OVERFLOW; hit = 0u; t2 = PT_T_OVERFLOW; best_inside = false; } // the exact role redoes the query (rt_persistent.h)
-                if (went == PT_WIDE_FULL || (went == PT_WIDE_NONE && sp == 0)) {
-                    p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
-                    if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_TRACE_STEP);
-                    active = false; fin = l;
-                } else if (went == PT_WIDE_NONE) cur = stack[--sp][lane];
+                if (went == PT_WIDE_FULL) { best_t = PT_T_OVERFLOW; hit = 0u; t2 = PT_T_OVERFLOW; best_inside = false; pend = RT_EMPTY_LEAF; done(); } // the exact role redoes the query (rt_persistent.h)
+                else if (went == PT_WIDE_NONE) {
+                    if (sp != 0) cur = stack[--sp][lane];
+                    else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
+                    else done();
+                }
             }
         }
-        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
-            if (cur != RT_EMPTY_LEAF) {
-                uint32_t i = cur & ~RT_LEAF_BIT;
+        if (active && pend != RT_EMPTY_LEAF) { // phase 2: leaves
+            {
+                uint32_t i = pend & ~RT_LEAF_BIT;
                 for (;;) {
                     Tri6Regs T = load_tri6(S.tris + i);
                     if (COUNT) n_tris++;
@@ -364,11 +375,8 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     i++;
                 }
             }
-            if (sp == 0) {
-                p6_rec(W, slot)[2] = make_float4(best_t, __uint_as_float(hit), __uint_as_float(best_inside ? 1u : 0u), t2);
-                if (P.group_cost) atomicAdd(&sh.cost[l >> pt_gshift(sh)], steps * P6_COST_TRACE_STEP);
-                active = false; fin = l;
-            } else cur = stack[--sp][lane];
+            pend = RT_EMPTY_LEAF;
+            if (cur == PT_DRAINED) done();
         }
     }
 }
@@ -382,7 +390,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     bool active = false, refill_ok = true, many = false, fragile = false; // fragile: a hit at a box boundary, the sum goes to the exact walk
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, idx0 = 0, idx1 = 0, idx2 = 0, idx3 = 0; // fin: the lane's finished, unpublished path; bit 31 = it goes to the slow role
     int sp = 0, k = 0;
-    uint32_t steps = 0;
+    uint32_t steps = 0, pend = RT_EMPTY_LEAF; // pend: the leaf this lane has met and not yet tested
     float term0 = 0.f, term1 = 0.f, term2 = 0.f, term3 = 0.f;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayGrid ray = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}; // idle lanes: never used
@@ -434,7 +442,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
-        if (idle && (__popcll(idle) >= P.refill || idle == ~0ull)) {
+        if (idle && (__popcll(idle) >= (P.refill >> 16) || idle == ~0ull)) {
             if (__ballot(fin != PT_NONE)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 const bool slow = fin != PT_NONE && (fin >> 31) != 0u;
@@ -455,7 +463,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     o = f3(q4.x, q4.y, q4.z); d = f3(q0.w, q1.x, q1.y);                        // the pdf's ray: x + eps*n towards the sampled direction
                     ray = make_ray_grid(S.grid, o, d);
                     steps = 0;
-                    cur = 0; sp = 0; k = 0; many = false; fragile = false; term0 = 0.f; term1 = 0.f;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; k = 0; many = false; fragile = false; term0 = 0.f; term1 = 0.f;
                     active = true;
                 }
             }
@@ -463,23 +471,29 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         const unsigned long long m_active = __ballot(active);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
-        for (;;) { // phase 1: inner nodes
+        for (;;) { // phase 1: inner nodes; a leaf waits in `pend` for the next leaf phase (rt_persistent.h, pt_trace_stint)
+            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) {
+                pend = cur;
+                cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
+                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) finish();
+            }
             const bool inner = active && !(cur & RT_LEAF_BIT);
             if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (inner) {
                 if (COUNT) n_nodes++;
                 steps++;
                 const int went = pt_wide_step_all(S.fast_light_nodes4, ray, stack, lane, sp, P6_STACK, cur);
-                if (went == PT_WIDE_FULL) { many = true; fragile = false; k = RT6_MAX_LIGHT_HITS + 1; finish(); } // the slow role walks the sum in the reference's order
+                if (went == PT_WIDE_FULL) { many = true; fragile = false; k = RT6_MAX_LIGHT_HITS + 1; pend = RT_EMPTY_LEAF; finish(); } // the slow role walks the sum in the reference's order
                 else if (went == PT_WIDE_NONE) {
-                    if (sp == 0) finish();
-                    else cur = stack[--sp][lane];
+                    if (sp != 0) cur = stack[--sp][lane];
+                    else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
+                    else finish();
                 }
             }
         }
-        if (active && (cur & RT_LEAF_BIT)) { // phase 2: leaves
-            if (cur != RT_EMPTY_LEAF) {
-                uint32_t i = cur & ~RT_LEAF_BIT;
+        if (active && pend != RT_EMPTY_LEAF) { // phase 2: leaves
+            {
+                uint32_t i = pend & ~RT_LEAF_BIT;
                 for (;;) {
                     Tri6Regs T = load_tri6(S.fast_lights + i);
                     if (COUNT) n_tris++;
@@ -511,8 +525,8 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     i++;
                 }
             }
-            if (sp == 0 || k > RT6_MAX_LIGHT_HITS) finish();
-            else cur = stack[--sp][lane];
+            pend = RT_EMPTY_LEAF;
+            if (cur == PT_DRAINED || k > RT6_MAX_LIGHT_HITS) finish();
         }
     }
 }

@@ -867,7 +867,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + ((size_t)pass_groups << sub), *d_ids = d_ofs + n_blocks_max + 1;
     dev::PtParams P{};
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
-    P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL);
+    P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL) | (env_int("RTAMD_LIGHT_REFILL", env_int("RTAMD_TRACE_REFILL", WF_REFILL)) << 16);
     P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
     P.shade_min = 0; // set per pass below
     P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
@@ -995,7 +995,7 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
     uint32_t *d_cost = scene->pt_groups, *d_ofs = d_cost + ((size_t)pass_groups << sub), *d_ids = d_ofs + n_blocks_max + 1;
     dev::PtParams P{};
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
-    P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL);
+    P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL) | (env_int("RTAMD_LIGHT_REFILL", env_int("RTAMD_TRACE_REFILL", WF_REFILL)) << 16);
     P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
     P.shade_min = 0; // set per pass below
     P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
@@ -1295,6 +1295,17 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
                             100 * h_cnt[16] / tt, 100 * h_cnt[17] / tt, 100 * h_cnt[18] / tt, 100 * h_cnt[19] / tt, 100 * h_cnt[20] / tt,
                             (double)h_cnt[22] / (double)(h_cnt[21] ? h_cnt[21] : 1), h_cnt[21], (double)h_cnt[24] / (double)(h_cnt[23] ? h_cnt[23] : 1), h_cnt[23],
                             h_cnt[25], h_cnt[26], (double)h_cnt[27] / (double)(h_cnt[26] ? h_cnt[26] : 1));
+                    for (int w = 0; w < 2; w++) {
+                        const double tw = (double)(h_cnt[48 + 3 * w] + h_cnt[49 + 3 * w] + h_cnt[50 + 3 * w]);
+                        fprintf(stderr, "[rtamd]   %s walker's wave time: hand-off and refill %.1f %%, inner nodes %.1f %%, leaves %.1f %%; leaf passes %llu with %.1f of 64 lanes\n",
+                                w ? "light" : "closest-hit", 100 * h_cnt[48 + 3 * w] / tw, 100 * h_cnt[49 + 3 * w] / tw, 100 * h_cnt[50 + 3 * w] / tw,
+                                h_cnt[54 + 2 * w], (double)h_cnt[55 + 2 * w] / (double)(h_cnt[54 + 2 * w] ? h_cnt[54 + 2 * w] : 1));
+                    }
+                    fprintf(stderr, "[rtamd]   closest-hit walker's hand-off points: %llu; of their time: publishing finished walks %.1f %%, taking new ones from the bitmap %.1f %%, reading their rays %.1f %% (the rest: the test itself)\n",
+                            h_cnt[63], 100.0 * h_cnt[60] / (double)(h_cnt[48] ? h_cnt[48] : 1), 100.0 * h_cnt[61] / (double)(h_cnt[48] ? h_cnt[48] : 1), 100.0 * h_cnt[62] / (double)(h_cnt[48] ? h_cnt[48] : 1));
+                    fprintf(stderr, "[rtamd]   light tests %llu (%.2f per light sum), hits %llu (%.2f per light sum); triangle tests of closest-hit walks %llu (%.2f per query)\n",
+                            h_cnt[59], (double)h_cnt[59] / (double)(h_cnt[1] ? h_cnt[1] : 1), h_cnt[58], (double)h_cnt[58] / (double)(h_cnt[1] ? h_cnt[1] : 1),
+                            h_cnt[3] - h_cnt[59], (double)(h_cnt[3] - h_cnt[59]) / (double)(h_cnt[0] ? h_cnt[0] : 1));
                 }
                 if (const char *dump = getenv("RTAMD_DUMP_WG")) { // diagnostic: start / exit time (ms after the first start) and paths of every workgroup of the last launch
                     if (FILE *f = fopen(dump, "w")) {

@@ -1,0 +1,16 @@
+set -o pipefail
+mkdir -p gpurun_out
+L=gpurun_out/r3_probe28.log
+: > $L
+for rep in 1 2; do
+for v in "" _nopp; do
+echo "== lib$v" >> $L
+RTAMD_LIB=$PWD/raytracing-course-hw_amd/librtamd$v.so timeout -k 10 200 python tools/tuning/pt_probe.py --spp 256 --reps 2 "" >> $L 2>&1 || exit $?
+done
+done
+echo "== counters" >> $L
+RTAMD_DEBUG_COUNTERS=1 timeout -k 10 200 python tools/tuning/pt_probe.py --spp 32 --reps 1 --counters "" >> $L 2>&1 || exit $?
+grep "==\|Msamples\|wave time\|light tests" $L | sed 's/, pipeline 2//; s/; exact closest.*//'
+timeout -k 10 600 python -m pytest tests/test_gpu_scenes.py tests/test_gpu_device_bvh.py -x -q > gpurun_out/r3_t25.log 2>&1; rc=$?
+tail -3 gpurun_out/r3_t25.log
+exit $rc

@@ -224,21 +224,31 @@ typedef float rt_f2 __attribute__((ext_vector_type(2)));
 // — and relative errors of the subtraction, of 1/d' (two roundings beside the reciprocal's) and of the product, 5 * 2^-24 of a
 // slab's t: since origin and box both lie on the grid, that t is at most 65,536 cells' worth along its axis, so 0.02 cells.  The extra
 // cell on either side of every box (rt_node_grid.h grid_axis_word) covers both, and the interval needs no widening of its own.
-struct RayGrid { float ox, oy, oz, ix, iy, iz; };
+// sx, sy, sz: byte selectors (v_perm_b32) that put the slab the ray meets first into the low half of a record's axis word — lo | hi << 16
+// as stored for a direction component >= 0, the halves swapped for a negative one — so that the test needs no min / max per axis.
+struct RayGrid { float ox, oy, oz, ix, iy, iz; uint32_t sx, sy, sz; };
+RT_DEV RayGrid ray_grid_idle() { // what an idle lane holds (never used); field by field: an aggregate constant would be copied from memory
+    RayGrid g;
+    g.ox = 0.f; g.oy = 0.f; g.oz = 0.f; g.ix = 1.f; g.iy = 1.f; g.iz = 1.f; g.sx = 0x03020100u; g.sy = 0x03020100u; g.sz = 0x03020100u;
+    return g;
+}
+#define RT_GRID_RAY_IDLE ray_grid_idle()
 RT_DEV RayGrid make_ray_grid(const NodeGrid &G, F3 o, F3 d) {
     const RayInv r = make_ray_inv(o, d);
     RayGrid g;
     g.ox = (o.x - G.lo[0]) * G.istep[0]; g.oy = (o.y - G.lo[1]) * G.istep[1]; g.oz = (o.z - G.lo[2]) * G.istep[2];
     g.ix = G.step[0] * r.inv.x; g.iy = G.step[1] * r.inv.y; g.iz = G.step[2] * r.inv.z;
+    g.sx = g.ix < 0.f ? 0x01000302u : 0x03020100u; g.sy = g.iy < 0.f ? 0x01000302u : 0x03020100u; g.sz = g.iz < 0.f ? 0x01000302u : 0x03020100u;
     return g;
 }
 // b = one child record of a GpuNode4Q: x, y, z words (lo | hi << 16) and the child word.  Pairs (lo, hi) per axis: packed subtract and multiply.
 RT_DEV bool slab_test_q(uint4 b, const RayGrid &r, float tbest, float &tnear) {
-    const rt_f2 x = (rt_f2{(float)(b.x & 0xFFFFu), (float)(b.x >> 16)} - r.ox) * r.ix;
-    const rt_f2 y = (rt_f2{(float)(b.y & 0xFFFFu), (float)(b.y >> 16)} - r.oy) * r.iy;
-    const rt_f2 z = (rt_f2{(float)(b.z & 0xFFFFu), (float)(b.z >> 16)} - r.oz) * r.iz;
-    const float tmin = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
-    const float tmax = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
+    const uint32_t wx = __builtin_amdgcn_perm(b.x, b.x, r.sx), wy = __builtin_amdgcn_perm(b.y, b.y, r.sy), wz = __builtin_amdgcn_perm(b.z, b.z, r.sz);
+    const rt_f2 x = (rt_f2{(float)(wx & 0xFFFFu), (float)(wx >> 16)} - r.ox) * r.ix; // (entry, exit) along x: the products keep that order
+    const rt_f2 y = (rt_f2{(float)(wy & 0xFFFFu), (float)(wy >> 16)} - r.oy) * r.iy;
+    const rt_f2 z = (rt_f2{(float)(wz & 0xFFFFu), (float)(wz >> 16)} - r.oz) * r.iz;
+    const float tmin = fmaxf(fmaxf(x.x, y.x), z.x);
+    const float tmax = fminf(fminf(x.y, y.y), z.y);
     tnear = tmin;
     return (tmin <= tmax) & (tmax >= 0.f) & (tmin <= tbest);
 }

@@ -157,7 +157,7 @@ RT_DEV int pt_wide_step_all(const GpuNode4Q *nodes, const RayGrid &ray, uint32_t
 }
 #if PT_QUANT_NODES
 typedef RayGrid PtRay;
-#define PT_RAY_IDLE {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}
+#define PT_RAY_IDLE RT_GRID_RAY_IDLE
 RT_DEV PtRay pt_make_ray(const SceneView &S, F3 o, F3 d) { return make_ray_grid(S.grid, o, d); }
 #else
 typedef RayInv PtRay;
@@ -241,8 +241,20 @@ RT_DEV uint32_t pt_rank_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Hands paths to the lanes that want one.  The wave reads 64 bitmap words at once (lane i: word cursor + i), then takes whole
-// words in order — ONE atomicAnd per word by lane 0 — and deals the claimed bits to the wanting lanes by rank, so a wave that
+// Exclusive prefix sum over the wave of a small count per lane (0..63), without LDS: one ballot per bit of the counts.  `total` is wave-uniform.
+RT_DEV int pt_prefix(int x, int &total) {
+    int before = 0;
+    total = 0;
+    for (int b = 0; b < 6; b++) {
+        const unsigned long long m = __ballot((x >> b) & 1);
+        before += (int)pt_rank_below(m) << b;
+        total += __popcll(m) << b;
+    }
+    return before;
+}
+
+// Hands paths to the lanes that want one.  The wave reads 64 bitmap words at once (lane i: word cursor + i), then the words
+// claim for themselves — one LDS atomic instruction for all of them — and the claimed bits are dealt to the wanting lanes by rank, so a wave that
 // wants 64 paths from a dense queue gets the two words of one 8x8 sub-tile (coherent rays) for two LDS atomics.  A word that
 // holds more paths than are wanted keeps its upper bits and the cursor stays on it, so the next request starts there (no
 // path is passed over).  Returns the local path index or PT_NONE.
@@ -255,34 +267,51 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
     const int need = __popcll(wantmask);
     const int my_rank = (int)pt_rank_below(wantmask);
     uint32_t got = PT_NONE;
-    int have = 0;                                                 // wave-uniform, like everything below but `got` (readlane / readfirstlane: SGPRs)
+    int have = 0;                                                 // wave-uniform, like everything below that is not per word (= per lane) or `got`
     for (uint32_t swept = 0; swept < nw && have < need; swept += 64u) {
         uint32_t w = cursor + lane;
         bool valid = true;
         if (nw >= 64u) { if (w >= nw) w -= nw; }
         else { valid = lane < nw; w = w % nw; }
         const uint32_t v = valid ? bm[w] : 0u;
-        unsigned long long nz = __ballot(v != 0u);
+        // Every word claims for itself, all in ONE LDS atomic of the wave: word i may take what the words before it leave of the request
+        // (a prefix sum of the words' bit counts).  A claim can come back short (another wave was faster); the sweep then goes on.
+        const int pc = __popc(v);
+        int in_sight;
+        const int before = pt_prefix(pc, in_sight);
         uint32_t next_cursor = cursor + 64u;
-        while (nz && have < need) {
-            const int j = __ffsll((long long)nz) - 1;
-            nz &= nz - 1ull;
-            const uint32_t vj = (uint32_t)__builtin_amdgcn_readlane((int)v, j), wj = (uint32_t)__builtin_amdgcn_readlane((int)w, j);
-            uint32_t rest = vj;                                   // the lowest (need - have) set bits of vj
-            for (int n = need - have; n > 0 && rest; n--) rest &= rest - 1u;
-            const uint32_t take = vj & ~rest;
-            uint32_t old = 0;
-            if (lane == 0) old = atomicAnd(&bm[wj], ~take);
-            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old) & take; // the bits this wave really claimed
-            const int c = __popc(old);
-            if (want && my_rank >= have && my_rank < have + c) {
-                uint32_t bits = old;
-                for (int k = my_rank - have; k > 0; k--) bits &= bits - 1u;
-                got = wj * 32u + (uint32_t)__ffs((int)bits) - 1u;
+        if (in_sight) {
+            const int room = need - have - before;
+            uint32_t take = 0u;
+            if (pc > 0 && room > 0) {
+                take = v;
+                if (room < pc) {                                  // the one word that is cut: its lowest `room` set bits
+                    uint32_t rest = v;
+                    for (int n = room; n > 0; n--) rest &= rest - 1u;
+                    take = v & ~rest;
+                }
             }
-            have += c;
-            if (rest) next_cursor = wj;                          // paths left in this word: come back to it first
-            else if (have >= need) next_cursor = wj + 1u;
+            uint32_t old = 0u;
+            if (take) old = atomicAnd(&bm[w], ~take) & take;     // the bits this word really gave
+            int claimed;
+            const int first = pt_prefix(__popc(old), claimed);   // this word's paths go to the wanting lanes of ranks have + first, ...
+            for (unsigned long long cm = __ballot(old != 0u); cm; cm &= cm - 1ull) {
+                const int j = __ffsll((long long)cm) - 1;
+                const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)old, j), wj = (uint32_t)__builtin_amdgcn_readlane((int)w, j);
+                const int fj = have + __builtin_amdgcn_readlane(first, j);
+                if (want && my_rank >= fj && my_rank < fj + __popc(oj)) {
+                    uint32_t bits = oj;
+                    for (int k = my_rank - fj; k > 0; k--) bits &= bits - 1u;
+                    got = wj * 32u + (uint32_t)__ffs((int)bits) - 1u;
+                }
+            }
+            have += claimed;
+            const unsigned long long tm = __ballot(take != 0u);
+            if (tm && have >= need) {                             // done: the next request starts at the last word touched if it kept paths, else behind it
+                const int jl = 63 - __clzll((long long)tm);
+                const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, jl), left = (uint32_t)__builtin_amdgcn_readlane((int)(v & ~take), jl);
+                next_cursor = left ? wl : wl + 1u;
+            }
         }
         cursor = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_cursor);
         if (cursor >= nw) cursor %= nw;

@@ -298,7 +298,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     uint32_t steps = 0; // node steps + triangle tests of the lane's walk: the cost measure of the re-deal
     uint32_t pend = RT_EMPTY_LEAF; // the leaf this lane has met and not yet tested
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayGrid ray = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}; // idle lanes: never used
+    RayGrid ray = RT_GRID_RAY_IDLE; // idle lanes: never used
     float best_t = RT_T_MAX, cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // look-behind and runner-up: rt_exact.h
     for (;;) {
         const unsigned long long idle = __ballot(!active);
@@ -393,7 +393,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     uint32_t steps = 0, pend = RT_EMPTY_LEAF; // pend: the leaf this lane has met and not yet tested
     float term0 = 0.f, term1 = 0.f, term2 = 0.f, term3 = 0.f;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
-    RayGrid ray = {0.f, 0.f, 0.f, 1.f, 1.f, 1.f}; // idle lanes: never used
+    RayGrid ray = RT_GRID_RAY_IDLE; // idle lanes: never used
     // where the lights x < y of the reference order separate in the reference's light tree (SceneView6::light_sep, see p6_merge_hits)
     auto sep = [&](uint32_t x, uint32_t y) {
         const uint32_t lv = 31u - (uint32_t)__clz((int)(y - x));

@@ -89,6 +89,14 @@ namespace dev {
 #undef PT_POSTPONE
 #define PT_POSTPONE 0          // the two-box float path keeps the plain loop
 #endif
+#ifndef PT_PEND_SLOTS
+#define PT_PEND_SLOTS 2        // leaves a lane may hold for the next leaf phase (2 or 3)
+#endif
+#if PT_PEND_SLOTS == 3
+#define PT_LAST_SLOT pend3
+#else
+#define PT_LAST_SLOT pend2
+#endif
 #define PT_DRAINED 0xFFFFFFFEu        // `cur` of a lane whose stack is empty and whose last leaf is still to be tested (reads as a leaf: the lane waits)
 #define PT_T_OVERFLOW (-1.f)          // t of a closest-hit record whose walk ran out of stack: the exact role redoes the query
 // ---- one step of a walk over the four-wide grid nodes (rt_types.h GpuNode4Q), shared with rt_persistent_hw6.h ------------------------
@@ -236,6 +244,8 @@ RT_DEV int pt_leaf_batch(int leaf_batch, unsigned long long m_active) {
     return share < cap ? share : cap;
 }
 
+// The wave's mask of a predicate, straight from the compare (HIP's __ballot takes an int: a select and a second compare per call).
+RT_DEV unsigned long long pt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // Number of set bits of a wave mask below this lane (v_mbcnt: no 64-bit lane mask in registers).
 RT_DEV uint32_t pt_rank_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -246,7 +256,7 @@ RT_DEV int pt_prefix(int x, int &total) {
     int before = 0;
     total = 0;
     for (int b = 0; b < 6; b++) {
-        const unsigned long long m = __ballot((x >> b) & 1);
+        const unsigned long long m = pt_ballot((x >> b) & 1);
         before += (int)pt_rank_below(m) << b;
         total += __popcll(m) << b;
     }
@@ -263,7 +273,7 @@ RT_DEV int pt_prefix(int x, int &total) {
 RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &cursor, bool want, bool from_start = false) {
     const uint32_t lane = threadIdx.x & 63u;
     if (from_start) cursor = 0u;
-    const unsigned long long wantmask = __ballot(want);
+    const unsigned long long wantmask = pt_ballot(want);
     const int need = __popcll(wantmask);
     const int my_rank = (int)pt_rank_below(wantmask);
     uint32_t got = PT_NONE;
@@ -295,7 +305,7 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
             if (take) old = atomicAnd(&bm[w], ~take) & take;     // the bits this word really gave
             int claimed;
             const int first = pt_prefix(__popc(old), claimed);   // this word's paths go to the wanting lanes of ranks have + first, ...
-            for (unsigned long long cm = __ballot(old != 0u); cm; cm &= cm - 1ull) {
+            for (unsigned long long cm = pt_ballot(old != 0u); cm; cm &= cm - 1ull) {
                 const int j = __ffsll((long long)cm) - 1;
                 const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)old, j), wj = (uint32_t)__builtin_amdgcn_readlane((int)w, j);
                 const int fj = have + __builtin_amdgcn_readlane(first, j);
@@ -306,7 +316,7 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
                 }
             }
             have += claimed;
-            const unsigned long long tm = __ballot(take != 0u);
+            const unsigned long long tm = pt_ballot(take != 0u);
             if (tm && have >= need) {                             // done: the next request starts at the last word touched if it kept paths, else behind it
                 const int jl = 63 - __clzll((long long)tm);
                 const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, jl), left = (uint32_t)__builtin_amdgcn_readlane((int)(v & ~take), jl);
@@ -323,7 +333,7 @@ RT_DEV uint32_t pt_pop(uint32_t *bm, int *cnt, const uint32_t nw, uint32_t &curs
 // Sets the bit of path l in queue q for the lanes with `doit` (wave-uniform call).
 template <class SH> RT_DEV void pt_push(SH &sh, int q, uint32_t l, bool doit) {
     if (doit) atomicOr(&sh.need[q][l >> 5], 1u << (l & 31u));
-    const unsigned long long m = __ballot(doit);
+    const unsigned long long m = pt_ballot(doit);
     if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sh.cnt[q], (int)__popcll(m));
 }
 
@@ -350,7 +360,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     bool active = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
     int sp = 0;
-    uint32_t pend = RT_EMPTY_LEAF; (void)pend; // PT_POSTPONE: the leaf this lane has met and not yet tested
+    uint32_t pend = RT_EMPTY_LEAF, pend2 = RT_EMPTY_LEAF, pend3 = RT_EMPTY_LEAF; (void)pend; (void)pend2; (void)pend3; // PT_POSTPONE: the leaves this lane has met and not yet tested (pend first)
     uint32_t steps = 0;   // node steps + triangle tests of the lane's current walk: the cost measure of the re-deal (PT_COST_*)
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     PtRay ray = PT_RAY_IDLE; // idle lanes: never used
@@ -364,13 +374,13 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     };
     PtLap<COUNT> clk;
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = pt_ballot(!active);
         if (idle && (__popcll(idle) >= (P.refill & 0xFFFF) || idle == ~0ull)) {
             // Hand-off point.  Finished lanes are published here and not the moment they finish: the release (a wait for the
             // wave's outstanding record stores) is paid once per refill, when the stores have long landed, not once per walk.
             PtLap<COUNT> sub;
             if (COUNT) prof.refills[0]++;
-            if (__ballot(fin != PT_NONE)) {
+            if (pt_ballot(fin != PT_NONE)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
                 fin = PT_NONE;
@@ -382,7 +392,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 sub.lap(prof.t_sub[0][1]);
-                n_queries += __popcll(__ballot(got != PT_NONE));
+                n_queries += __popcll(pt_ballot(got != PT_NONE));
                 if (got != PT_NONE) {
                     l = got; slot = pt_slot(sh, l);
                     const float4 *r = wf_rec(W, slot);
@@ -391,13 +401,13 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     ray = pt_make_ray(S, o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     steps = 0;
-                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                     active = true;
                 }
                 if (COUNT) { asm volatile("" : "+v"(ray.ix)); sub.lap(prof.t_sub[0][2]); }
             }
         }
-        const unsigned long long m_active = __ballot(active);
+        const unsigned long long m_active = pt_ballot(active);
         clk.lap(prof.t_part[0][0]);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
@@ -405,15 +415,15 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #if PT_POSTPONE
             // A lane that meets a leaf keeps it for the next leaf phase and walks on with what its stack holds (a second leaf stops it):
             // more lanes stay in the node loop, and more of them bring a leaf to each leaf phase.
-            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) {
-                pend = cur;
+            if (active && (cur & RT_LEAF_BIT) && PT_LAST_SLOT == RT_EMPTY_LEAF && cur != PT_DRAINED) {
+                if (pend == RT_EMPTY_LEAF) pend = cur; else if (pend2 == RT_EMPTY_LEAF) pend2 = cur; else pend3 = cur; // (an empty leaf leaves the slot as it was)
                 cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
                 if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) { store_hit(); active = false; fin = l; } // an empty leaf was all that was left
             }
 #endif
             const bool inner = active && !(cur & RT_LEAF_BIT);
-            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
-            if (COUNT) { prof.trace_iters++; prof.trace_lane_iters += __popcll(__ballot(inner)); }
+            if (!pt_ballot(inner) || __popcll(pt_ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (COUNT) { prof.trace_iters++; prof.trace_lane_iters += __popcll(pt_ballot(inner)); }
             if (inner) {
                 if (COUNT) n_nodes++;
                 steps += PT_COST_TRACE_NODE;
@@ -433,7 +443,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     // ray that grazes many boxes: triangle soups).  The walk ends here and says so — no hit has a negative t — and the
                     // exact role walks the query with a stack of its own (pt_exact_batch).
                     best_t = PT_T_OVERFLOW; best_u = 0.f; best_v = 0.f; hit = 0u; t2 = PT_T_OVERFLOW;
-                    store_hit(); active = false; fin = l; pend = RT_EMPTY_LEAF;
+                    store_hit(); active = false; fin = l; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;
                 }
 #else
                 float n0, n1;
@@ -459,11 +469,13 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #if PT_POSTPONE
         const bool at_leaf = active && pend != RT_EMPTY_LEAF;
         const uint32_t leaf = pend;
+        uint32_t more = pend2, more2 = pend3;
 #else
         const bool at_leaf = active && (cur & RT_LEAF_BIT);
         const uint32_t leaf = cur;
+        uint32_t more = RT_EMPTY_LEAF, more2 = RT_EMPTY_LEAF;
 #endif
-        if (COUNT) { prof.leaf_iters[0]++; prof.leaf_lane_iters[0] += __popcll(__ballot(at_leaf)); }
+        if (COUNT) { prof.leaf_iters[0]++; prof.leaf_lane_iters[0] += __popcll(pt_ballot(at_leaf)); }
         if (at_leaf) { // phase 2: leaves
             if (leaf != RT_EMPTY_LEAF) {
                 uint32_t i = leaf & ~RT_LEAF_BIT;
@@ -481,12 +493,13 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                             cull_t = t + fmaxf(S.cull_k * t, h_ray);
                         } else t2 = fminf(t2, t);
                     }
-                    if (T.pad & 1u) break;
-                    i++;
+                    if (!(T.pad & 1u)) i++;
+                    else if (more == RT_EMPTY_LEAF) break;
+                    else { i = more & ~RT_LEAF_BIT; more = more2; more2 = RT_EMPTY_LEAF; } // the lane's next leaf
                 }
             }
 #if PT_POSTPONE
-            pend = RT_EMPTY_LEAF;
+            pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;
             if (cur == PT_DRAINED) { store_hit(); active = false; fin = l; } // a lane that stopped at a second leaf keeps that for the next round
 #else
             if (sp == 0) {
@@ -507,7 +520,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     bool active = false, overflow = false, refill_ok = true;
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE; // fin: the lane's finished, unpublished path; bit 31 = it needs the exact role instead
     int sp = 0, k = 0;
-    uint32_t pend = RT_EMPTY_LEAF; (void)pend; // PT_POSTPONE: the leaf this lane has met and not yet tested
+    uint32_t pend = RT_EMPTY_LEAF, pend2 = RT_EMPTY_LEAF, pend3 = RT_EMPTY_LEAF; (void)pend; (void)pend2; (void)pend3; // PT_POSTPONE: the leaves this lane has met and not yet tested (pend first)
     uint32_t steps = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     PtRay ray = PT_RAY_IDLE; // idle lanes: never used
@@ -547,9 +560,9 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     };
     PtLap<COUNT> clk;
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = pt_ballot(!active);
         if (idle && (__popcll(idle) >= (P.refill >> 16) || idle == ~0ull)) {
-            if (__ballot(fin != PT_NONE)) { // hand-off point, see pt_trace_stint
+            if (pt_ballot(fin != PT_NONE)) { // hand-off point, see pt_trace_stint
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 const bool slow = (fin >> 31) != 0u && fin != PT_NONE;
                 pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE && !slow);
@@ -561,33 +574,33 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             else if (pt_count(&sh.cnt[PT_Q_LIGHT]) > 0) {
                 const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                n_queries += __popcll(__ballot(got != PT_NONE));
+                n_queries += __popcll(pt_ballot(got != PT_NONE));
                 if (got != PT_NONE) {
                     l = got; slot = pt_slot(sh, l);
                     const float4 *r = wf_rec(W, slot);
                     float4 q0 = r[0], q1 = r[1];
                     o = f3(q0.x, q0.y, q0.z); d = f3(q0.w, q1.x, q1.y);
                     ray = pt_make_ray(S, o, d);
-                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; k = 0; overflow = false; steps = 0;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF; k = 0; overflow = false; steps = 0;
                     active = true;
                 }
             }
         }
-        const unsigned long long m_active = __ballot(active);
+        const unsigned long long m_active = pt_ballot(active);
         clk.lap(prof.t_part[1][0]);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes
 #if PT_POSTPONE
-            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) { // the leaf waits for the next leaf phase (pt_trace_stint)
-                pend = cur;
+            if (active && (cur & RT_LEAF_BIT) && PT_LAST_SLOT == RT_EMPTY_LEAF && cur != PT_DRAINED) { // the leaf waits for the next leaf phase (pt_trace_stint)
+                if (pend == RT_EMPTY_LEAF) pend = cur; else if (pend2 == RT_EMPTY_LEAF) pend2 = cur; else pend3 = cur;
                 cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
                 if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) finish();
             }
 #endif
             const bool inner = active && !(cur & RT_LEAF_BIT);
-            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
-            if (COUNT) { prof.light_iters++; prof.light_lane_iters += __popcll(__ballot(inner)); }
+            if (!pt_ballot(inner) || __popcll(pt_ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (COUNT) { prof.light_iters++; prof.light_lane_iters += __popcll(pt_ballot(inner)); }
             if (inner) {
                 if (COUNT) n_nodes++;
                 steps += PT_COST_LIGHT_NODE;
@@ -602,7 +615,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     if (sp == 0) finish();
                     else cur = stack[--sp][lane];
 #endif
-                } else if (went == PT_WIDE_FULL) { overflow = true; pend = RT_EMPTY_LEAF; finish(); } // no room beside the hits: the slow role sums this query
+                } else if (went == PT_WIDE_FULL) { overflow = true; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF; finish(); } // no room beside the hits: the slow role sums this query
 #else
                 float n0, n1;
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_walk_nodes + cur);
@@ -622,11 +635,13 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #if PT_POSTPONE
         const bool at_leaf = active && pend != RT_EMPTY_LEAF;
         const uint32_t leaf = pend;
+        uint32_t more = pend2, more2 = pend3;
 #else
         const bool at_leaf = active && (cur & RT_LEAF_BIT);
         const uint32_t leaf = cur;
+        uint32_t more = RT_EMPTY_LEAF, more2 = RT_EMPTY_LEAF;
 #endif
-        if (COUNT) { prof.leaf_iters[1]++; prof.leaf_lane_iters[1] += __popcll(__ballot(at_leaf)); }
+        if (COUNT) { prof.leaf_iters[1]++; prof.leaf_lane_iters[1] += __popcll(pt_ballot(at_leaf)); }
         if (at_leaf) { // phase 2: leaves
             if (leaf != RT_EMPTY_LEAF) {
                 uint32_t i = leaf & ~RT_LEAF_BIT;
@@ -648,12 +663,13 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                             stack[P8_STACK - 1 - 2 * j][lane] = li; stack[P8_STACK - 2 - 2 * j][lane] = __float_as_uint(term); k++;
                         }
                     }
-                    if (last) break;
-                    i++;
+                    if (!last) i++;
+                    else if (more == RT_EMPTY_LEAF) break;
+                    else { i = more & ~RT_LEAF_BIT; more = more2; more2 = RT_EMPTY_LEAF; } // the lane's next leaf
                 }
             }
 #if PT_POSTPONE
-            pend = RT_EMPTY_LEAF;
+            pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;
             if (cur == PT_DRAINED) finish();
 #else
             if (sp == 0) finish();
@@ -848,7 +864,7 @@ RT_DEV void pt_exact_batch(const SceneView &S, const WfView &W, SH &sh, PtWave &
         float *pdf = reinterpret_cast<float *>(wf_entry(W, slot, depth)) + 3;
         *pdf = *pdf + v / S.n_lights_f;
     }
-    n_xlight += __popcll(__ballot(got != PT_NONE));
+    n_xlight += __popcll(pt_ballot(got != PT_NONE));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
     got = pt_pop(sh.need[PT_Q_XTRACE], &sh.cnt[PT_Q_XTRACE], wv.nw, wv.cur[PT_Q_XTRACE], lane < PT_EXACT_BATCH);
@@ -868,7 +884,7 @@ RT_DEV void pt_exact_batch(const SceneView &S, const WfView &W, SH &sh, PtWave &
         float *pk = reinterpret_cast<float *>(r + 3) + 3;
         *pk = __uint_as_float(__float_as_uint(*pk) | WF_VERIFIED_BIT);
     }
-    n_xtrace += __popcll(__ballot(got != PT_NONE));
+    n_xtrace += __popcll(pt_ballot(got != PT_NONE));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
 }
@@ -931,7 +947,7 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
                 started = true;
             }
         }
-        const unsigned long long m = __ballot(started);
+        const unsigned long long m = pt_ballot(started);
         if (m && lane == 0) atomicAdd(&sh.cnt[PT_N_LIVE], (int)__popcll(m));
         pt_push(sh, PT_Q_TRACE, l, started);
     }
@@ -982,7 +998,7 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
 #ifndef DBG_NO_SHADE
             if (got != PT_NONE) { PtPark pk; pk.p = (PtLdsWord)&stack[0][lane]; todo = pt_shade_lean<FEAT>(S, R, W, pt_slot(sh, got), pk, discarded); }
 #endif
-            n_discarded += __popcll(__ballot(discarded));
+            n_discarded += __popcll(pt_ballot(discarded));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             const bool next = got != PT_NONE && (todo & WF_NEXT_TRACE), with_light = next && (todo & WF_NEXT_LIGHT);
             if (next) atomicOr(&sh.pending[got >> 4], (PT_BIT_T | (with_light ? PT_BIT_L : 0u)) << ((got & 15u) * 2u));
@@ -990,11 +1006,11 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
             pt_push(sh, PT_Q_LIGHT, got, with_light);
             pt_push(sh, PT_Q_XTRACE, got, got != PT_NONE && todo == PT_SHADE_EXACT);
             if (got != PT_NONE && todo != PT_SHADE_EXACT) atomicAdd(&sh.cost[got >> pt_gshift(sh)], (uint32_t)PT_COST_SHADE);
-            const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == WF_PARKED)); // finished, or parked for the next phase
+            const unsigned long long done = pt_ballot(got != PT_NONE && (todo == 0 || todo == WF_PARKED)); // finished, or parked for the next phase
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;
             if (P.prio == 2) __builtin_amdgcn_s_setprio(0);
-            if (COUNT) { prof.shade_batches++; prof.shade_items += __popcll(__ballot(got != PT_NONE)); }
+            if (COUNT) { prof.shade_batches++; prof.shade_items += __popcll(pt_ballot(got != PT_NONE)); }
             lap(prof.t_shade);
             continue;
         }

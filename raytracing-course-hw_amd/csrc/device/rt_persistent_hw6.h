@@ -296,14 +296,14 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     bool best_inside = false;
     int sp = 0;
     uint32_t steps = 0; // node steps + triangle tests of the lane's walk: the cost measure of the re-deal
-    uint32_t pend = RT_EMPTY_LEAF; // the leaf this lane has met and not yet tested
+    uint32_t pend = RT_EMPTY_LEAF, pend2 = RT_EMPTY_LEAF; // the leaves this lane has met and not yet tested (pend first)
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayGrid ray = RT_GRID_RAY_IDLE; // idle lanes: never used
     float best_t = RT_T_MAX, cull_t = RT_T_MAX, t2 = 2.f * RT_T_MAX, h_ray = 0.f; // look-behind and runner-up: rt_exact.h
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = pt_ballot(!active);
         if (idle && (__popcll(idle) >= (P.refill & 0xFFFF) || idle == ~0ull)) {
-            if (__ballot(fin != PT_NONE)) { // hand-off point (rt_persistent.h)
+            if (pt_ballot(fin != PT_NONE)) { // hand-off point (rt_persistent.h)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 pt_complete(sh, fin, PT_BIT_T, fin != PT_NONE);
                 fin = PT_NONE;
@@ -313,7 +313,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
             else if (pt_count(&sh.cnt[PT_Q_TRACE]) > 0) {
                 const uint32_t got = pt_pop(sh.need[PT_Q_TRACE], &sh.cnt[PT_Q_TRACE], wv.nw, wv.cur[PT_Q_TRACE], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                n_queries += __popcll(__ballot(got != PT_NONE));
+                n_queries += __popcll(pt_ballot(got != PT_NONE));
                 if (got != PT_NONE) {
                     l = got; slot = pt_slot(sh, l);
                     const float4 *r = p6_rec(W, slot);
@@ -322,12 +322,12 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     ray = make_ray_grid(S.grid, o, d);
                     h_ray = S.exact_boxes ? pt_look_behind_abs(d, S.box_c2x) : 0.f;
                     steps = 0;
-                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; hit = 0xFFFFFFFFu; best_ref = 0xFFFFFFFFu; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_inside = false;
                     active = true;
                 }
             }
         }
-        const unsigned long long m_active = __ballot(active);
+        const unsigned long long m_active = pt_ballot(active);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         auto done = [&]() {
@@ -336,18 +336,18 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
             active = false; fin = l;
         };
         for (;;) { // phase 1: inner nodes; a leaf waits in `pend` for the next leaf phase while the lane walks on (rt_persistent.h, pt_trace_stint)
-            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) {
-                pend = cur;
+            if (active && (cur & RT_LEAF_BIT) && pend2 == RT_EMPTY_LEAF && cur != PT_DRAINED) {
+                if (pend == RT_EMPTY_LEAF) pend = cur; else pend2 = cur;
                 cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
                 if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) done();
             }
             const bool inner = active && !(cur & RT_LEAF_BIT);
-            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (!pt_ballot(inner) || __popcll(pt_ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (inner) {
                 if (COUNT) n_nodes++;
                 steps++;
                 const int went = pt_wide_step_nearest(S.nodes4, ray, cull_t, stack, lane, sp, P6_STACK, cur);
-                if (went == PT_WIDE_FULL) { best_t = PT_T_OVERFLOW; hit = 0u; t2 = PT_T_OVERFLOW; best_inside = false; pend = RT_EMPTY_LEAF; done(); } // the exact role redoes the query (rt_persistent.h)
+                if (went == PT_WIDE_FULL) { best_t = PT_T_OVERFLOW; hit = 0u; t2 = PT_T_OVERFLOW; best_inside = false; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; done(); } // the exact role redoes the query (rt_persistent.h)
                 else if (went == PT_WIDE_NONE) {
                     if (sp != 0) cur = stack[--sp][lane];
                     else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
@@ -357,7 +357,7 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         }
         if (active && pend != RT_EMPTY_LEAF) { // phase 2: leaves
             {
-                uint32_t i = pend & ~RT_LEAF_BIT;
+                uint32_t i = pend & ~RT_LEAF_BIT, more = pend2;
                 for (;;) {
                     Tri6Regs T = load_tri6(S.tris + i);
                     if (COUNT) n_tris++;
@@ -371,11 +371,12 @@ RT_DEV void p6_trace_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                             cull_t = S.exact_boxes ? t + fmaxf(S.cull_k * t, h_ray) : t;
                         } else t2 = fminf(t2, t);
                     }
-                    if (T.last) break;
-                    i++;
+                    if (!T.last) i++;
+                    else if (more == RT_EMPTY_LEAF) break;
+                    else { i = more & ~RT_LEAF_BIT; more = RT_EMPTY_LEAF; } // the lane's second leaf
                 }
             }
-            pend = RT_EMPTY_LEAF;
+            pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF;
             if (cur == PT_DRAINED) done();
         }
     }
@@ -390,7 +391,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
     bool active = false, refill_ok = true, many = false, fragile = false; // fragile: a hit at a box boundary, the sum goes to the exact walk
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE, idx0 = 0, idx1 = 0, idx2 = 0, idx3 = 0; // fin: the lane's finished, unpublished path; bit 31 = it goes to the slow role
     int sp = 0, k = 0;
-    uint32_t steps = 0, pend = RT_EMPTY_LEAF; // pend: the leaf this lane has met and not yet tested
+    uint32_t steps = 0, pend = RT_EMPTY_LEAF, pend2 = RT_EMPTY_LEAF; // pend, pend2: the leaves this lane has met and not yet tested
     float term0 = 0.f, term1 = 0.f, term2 = 0.f, term3 = 0.f;
     F3 o = f3(0.f, 0.f, 0.f), d = f3(0.f, 0.f, 1.f);
     RayGrid ray = RT_GRID_RAY_IDLE; // idle lanes: never used
@@ -441,9 +442,9 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         fin = l;
     };
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
+        const unsigned long long idle = pt_ballot(!active);
         if (idle && (__popcll(idle) >= (P.refill >> 16) || idle == ~0ull)) {
-            if (__ballot(fin != PT_NONE)) {
+            if (pt_ballot(fin != PT_NONE)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 const bool slow = fin != PT_NONE && (fin >> 31) != 0u;
                 pt_complete(sh, fin, PT_BIT_L, fin != PT_NONE && !slow);
@@ -455,7 +456,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
             else if (pt_count(&sh.cnt[PT_Q_LIGHT]) > 0) {
                 const uint32_t got = pt_pop(sh.need[PT_Q_LIGHT], &sh.cnt[PT_Q_LIGHT], wv.nw, wv.cur[PT_Q_LIGHT], !active, wv.front_first);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                n_queries += __popcll(__ballot(got != PT_NONE));
+                n_queries += __popcll(pt_ballot(got != PT_NONE));
                 if (got != PT_NONE) {
                     l = got; slot = pt_slot(sh, l);
                     const float4 *r = p6_rec(W, slot);
@@ -463,27 +464,27 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                     o = f3(q4.x, q4.y, q4.z); d = f3(q0.w, q1.x, q1.y);                        // the pdf's ray: x + eps*n towards the sampled direction
                     ray = make_ray_grid(S.grid, o, d);
                     steps = 0;
-                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; k = 0; many = false; fragile = false; term0 = 0.f; term1 = 0.f;
+                    cur = 0; sp = 0; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; k = 0; many = false; fragile = false; term0 = 0.f; term1 = 0.f;
                     active = true;
                 }
             }
         }
-        const unsigned long long m_active = __ballot(active);
+        const unsigned long long m_active = pt_ballot(active);
         if (!m_active) break;
         const int lb = pt_leaf_batch(P.leaf_batch, m_active);
         for (;;) { // phase 1: inner nodes; a leaf waits in `pend` for the next leaf phase (rt_persistent.h, pt_trace_stint)
-            if (active && (cur & RT_LEAF_BIT) && pend == RT_EMPTY_LEAF && cur != PT_DRAINED) {
-                pend = cur;
+            if (active && (cur & RT_LEAF_BIT) && pend2 == RT_EMPTY_LEAF && cur != PT_DRAINED) {
+                if (pend == RT_EMPTY_LEAF) pend = cur; else pend2 = cur;
                 cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
                 if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) finish();
             }
             const bool inner = active && !(cur & RT_LEAF_BIT);
-            if (!__ballot(inner) || __popcll(__ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
+            if (!pt_ballot(inner) || __popcll(pt_ballot(active && (cur & RT_LEAF_BIT))) >= lb) break;
             if (inner) {
                 if (COUNT) n_nodes++;
                 steps++;
                 const int went = pt_wide_step_all(S.fast_light_nodes4, ray, stack, lane, sp, P6_STACK, cur);
-                if (went == PT_WIDE_FULL) { many = true; fragile = false; k = RT6_MAX_LIGHT_HITS + 1; pend = RT_EMPTY_LEAF; finish(); } // the slow role walks the sum in the reference's order
+                if (went == PT_WIDE_FULL) { many = true; fragile = false; k = RT6_MAX_LIGHT_HITS + 1; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; finish(); } // the slow role walks the sum in the reference's order
                 else if (went == PT_WIDE_NONE) {
                     if (sp != 0) cur = stack[--sp][lane];
                     else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
@@ -493,7 +494,7 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         }
         if (active && pend != RT_EMPTY_LEAF) { // phase 2: leaves
             {
-                uint32_t i = pend & ~RT_LEAF_BIT;
+                uint32_t i = pend & ~RT_LEAF_BIT, more = pend2;
                 for (;;) {
                     Tri6Regs T = load_tri6(S.fast_lights + i);
                     if (COUNT) n_tris++;
@@ -521,11 +522,12 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
                         }
                         k++;
                     }
-                    if (T.last) break;
-                    i++;
+                    if (!T.last) i++;
+                    else if (more == RT_EMPTY_LEAF) break;
+                    else { i = more & ~RT_LEAF_BIT; more = RT_EMPTY_LEAF; } // the lane's second leaf
                 }
             }
-            pend = RT_EMPTY_LEAF;
+            pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF;
             if (cur == PT_DRAINED || k > RT6_MAX_LIGHT_HITS) finish();
         }
     }
@@ -781,7 +783,7 @@ template <class SH>
 RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &wv, P6Lds area, uint32_t got, bool mine, uint32_t &n_xlight) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t base = 0; base < 64u; base += P6_XBATCH) { // the wave's lanes take turns at the slices, eight at a time
-        if (!__ballot(mine && lane >= base && lane < base + P6_XBATCH)) continue;
+        if (!pt_ballot(mine && lane >= base && lane < base + P6_XBATCH)) continue;
         bool boundary = false;
         if (mine && lane >= base && lane < base + P6_XBATCH) {
             P6Slice sl; sl.p = area + (lane - base);
@@ -806,7 +808,7 @@ RT_DEV void p6_slow_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave &
             else v = light_pdf_sum6(S, lx, ld, sl);       // more hits than the record holds: the plain reference-order walk
             reinterpret_cast<float *>(r + 4)[3] = v;
         }
-        n_xlight += (uint32_t)__popcll(__ballot(boundary)); // wave-uniform
+        n_xlight += (uint32_t)__popcll(pt_ballot(boundary)); // wave-uniform
     }
 }
 
@@ -830,7 +832,7 @@ RT_DEV void p6_exact_batch(const SceneView6 &S, const W6View &W, SH &sh, PtWave 
         float *pk = reinterpret_cast<float *>(r + 3) + 3;
         *pk = __uint_as_float(__float_as_uint(*pk) | P6_VERIFIED);
     }
-    n_exact += __popcll(__ballot(got != PT_NONE));
+    n_exact += __popcll(pt_ballot(got != PT_NONE));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
 }
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
                 started = true;
             }
         }
-        const unsigned long long m = __ballot(started);
+        const unsigned long long m = pt_ballot(started);
         if (m && lane == 0) atomicAdd(&sh.cnt[PT_N_LIVE], (int)__popcll(m));
         pt_push(sh, PT_Q_TRACE, l, started);
     }
@@ -923,8 +925,8 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
                 if ((kw >> 31) || kw > (uint32_t)P6_MERGE_HITS) batch = true;
                 else reinterpret_cast<float *>(r + 4)[3] = p6_merge_hits(S, reinterpret_cast<const float2 *>(r + 48), (int)kw, stack);
             }
-            if (__ballot(batch)) p6_slow_batch(S, W, sh, wv, (P6Lds)&stack[0][0], got, batch, n_xlight); // the merges are done: their columns are free
-            n_slow += __popcll(__ballot(got != PT_NONE));
+            if (pt_ballot(batch)) p6_slow_batch(S, W, sh, wv, (P6Lds)&stack[0][0], got, batch, n_xlight); // the merges are done: their columns are free
+            n_slow += __popcll(pt_ballot(got != PT_NONE));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             pt_complete(sh, got, PT_BIT_L, got != PT_NONE);
             idle_spins = 0;
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(P6_THREADS, P6_PER_CU) void p6_persistent_kernel(Sc
             pt_push(sh, PT_Q_TRACE, got, tr);
             pt_push(sh, PT_Q_LIGHT, got, li);
             if (got != PT_NONE && todo != P6_EXACT) atomicAdd(&sh.cost[got >> pt_gshift(sh)], (uint32_t)P6_COST_SHADE);
-            const unsigned long long done = __ballot(got != PT_NONE && (todo == 0 || todo == P6_PARKED));
+            const unsigned long long done = pt_ballot(got != PT_NONE && (todo == 0 || todo == P6_PARKED));
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));
             idle_spins = 0;
             clock_role(2);

@@ -868,7 +868,7 @@ static void launch_persistent(rt_scene *scene, const SceneView &V, const RenderV
     dev::PtParams P{};
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
     P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL) | (env_int("RTAMD_LIGHT_REFILL", env_int("RTAMD_TRACE_REFILL", WF_REFILL)) << 16);
-    P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", 28) & 255) | (leaf_share << 16); // lanes that hold two leaves (or have nothing else left) before a leaf phase starts
     P.shade_min = 0; // set per pass below
     P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
     P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);
@@ -996,7 +996,7 @@ static void launch_persistent6(rt_scene *scene, const SceneView6 &V, const Rende
     dev::PtParams P{};
     const int leaf_share = env_int("RTAMD_WF_LEAF_SHARE_256", 112) & 0x7fff;
     P.refill = env_int("RTAMD_TRACE_REFILL", WF_REFILL) | (env_int("RTAMD_LIGHT_REFILL", env_int("RTAMD_TRACE_REFILL", WF_REFILL)) << 16);
-    P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", WF_LEAF_BATCH) & 255) | (leaf_share << 16);
+    P.leaf_batch = (env_int("RTAMD_TRACE_LEAF_BATCH", 28) & 255) | (leaf_share << 16); // lanes that hold two leaves (or have nothing else left) before a leaf phase starts
     P.shade_min = 0; // set per pass below
     P.shade_thr0 = env_int("RTAMD_PT_SHADE_THR0", 128);
     P.shade_thr_step = env_int("RTAMD_PT_SHADE_STEP", 512);

@@ -33,7 +33,8 @@ def main():
          "valu_busy_per_simd_pct": round(100 * valu_per_wave * waves_per_simd, 1),           # x resident waves: how busy the SIMD's VALU is
          "valu_lanes_active_pct": round(100 * tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 1),
          "l2_hit_pct": round(100 * tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 1),
-         "verdict": "latency x VALU issue on a cache-resident working set (98 MB scene in the Infinity Cache, tree tops in L2): not HBM bandwidth",
+         "verdict": ("VALU issue" if valu_per_wave * waves_per_simd > 0.85 else "latency x VALU issue") +
+                    " on a cache-resident working set (98 MB scene in the Infinity Cache, tree tops in L2): not HBM bandwidth",
          "source": "rocprofv3 --pmc SQ_* / TCC_* passes (counters only, --kernel-trace) of `bench.py --steps 1 --warmup 0 --spp 16 --no-cpu-baseline`, tools/profiling/profile_bench.sh"}
     json.dump(j, open(out, "w"), indent=1)
     print(json.dumps(j))

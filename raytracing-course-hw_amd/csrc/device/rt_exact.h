@@ -212,6 +212,31 @@ RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2
 // the light triangle's own box: a, a + b, a + c).
 // `index`: the light's position in the reference's light order — carried by the record itself (pad >> 1) in the persistent kernel's own light
 // tree (SceneView::lights_walk), whose leaf order is not the light order.
+// The same in two steps, for a leaf loop that tests several lights and leaves the (rarer, longer) work on a hit for after the loop:
+// pt_light_test is the triangle test alone, pt_light_pdf_hit what light_pdf_one computes once the test has passed.
+RT_DEV bool pt_light_test(const LightRec *L, F3 x, F3 d, bool &last, uint32_t &index, float &t, float &u, float &v, bool &inside) {
+    const TriIsect T = load_isect(&L->isect);
+    last = (T.pad & 1u) != 0;
+    index = T.pad >> 1;
+    return tri_test(T, x, d, t, u, v, inside);
+}
+RT_DEV float pt_light_pdf_hit(const SceneView &S, const LightRec *L, F3 x, F3 d, float t, float u, float v, bool inside, bool &robust) {
+    robust = true;
+    const float4 *q = reinterpret_cast<const float4 *>(L) + 3;
+    float4 q1 = q[1], q2 = q[2], q3 = q[3];
+    float point_prob = q1.z;
+    F3 n3 = f3(q1.w, q2.x, q2.y), dn1 = f3(q2.z, q2.w, q3.x), dn2 = f3(q3.y, q3.z, q3.w);
+    F3 sn = n3 + u * dn1 + v * dn2;           // primitives.cpp:110
+    sn = normalize(sn);                        // :117
+    if (inside) sn = neg(sn);                  // :118-119
+    if (S.hw7) { const TriIsect T = load_isect(&L->isect); F3 n = f3(T.nx, T.ny, T.nz); sn = normalize(inside ? neg(n) : n); }
+    F3 y = x + t * d;                          // distributions.h:144
+    if (S.exact_boxes == 1u) {
+        const float4 blo = q[4], bhi = q[5];   // the light's own box (LightRec::box_lo / box_hi)
+        robust = pt_box_robust(f3(blo.x, blo.y, blo.z), f3(bhi.x, bhi.y, bhi.z), y, d, t, S.box_c2);
+    }
+    return point_prob * len2(x - y) / fabsf(dot(d, sn)); // :68-70 (pdfOne, shading normal in hw8)
+}
 RT_DEV float pt_light_pdf_one(const SceneView &S, const LightRec *L, F3 x, F3 d, bool &last, bool &robust, uint32_t &index) {
     TriIsect T = load_isect(&L->isect);
     last = (T.pad & 1u) != 0;

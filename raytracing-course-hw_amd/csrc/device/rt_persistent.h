@@ -90,7 +90,7 @@ namespace dev {
 #define PT_POSTPONE 0          // the two-box float path keeps the plain loop
 #endif
 #ifndef PT_PEND_SLOTS
-#define PT_PEND_SLOTS 2        // leaves a lane may hold for the next leaf phase (2 or 3)
+#define PT_PEND_SLOTS 3        // leaves a lane may hold for the next leaf phase (2 or 3)
 #endif
 #if PT_PEND_SLOTS == 3
 #define PT_LAST_SLOT pend3
@@ -256,6 +256,7 @@ RT_DEV int pt_prefix(int x, int &total) {
     int before = 0;
     total = 0;
     for (int b = 0; b < 6; b++) {
+        if (!pt_ballot((x >> b) != 0)) break;      // no lane has a bit at or above b (sparse queues: one or two rounds)
         const unsigned long long m = pt_ballot((x >> b) & 1);
         before += (int)pt_rank_below(m) << b;
         total += __popcll(m) << b;
@@ -645,28 +646,41 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
         if (at_leaf) { // phase 2: leaves
             if (leaf != RT_EMPTY_LEAF) {
                 uint32_t i = leaf & ~RT_LEAF_BIT;
-                for (;;) {
-                    bool last, robust; uint32_t li;
-                    if (COUNT) { n_tris++; prof.light_tests++; }
-                    steps += PT_COST_LIGHT_TEST;
-                    float term = pt_light_pdf_one(S, S.lights_walk + i, o, d, last, robust, li);
+                // The loop only tests; what a hit needs beyond the test (the rest of the light's record, the pdf term, the robustness test, the
+                // sorted insertion) waits until after the loop — a lane rarely hits twice in one leaf phase, and the long hit code then runs once
+                // per phase instead of once per tested light.
+                bool held = false; uint32_t h_i = 0u, h_li = 0u; float h_t = 0.f, h_u = 0.f, h_v = 0.f; bool h_in = false;
+                auto take = [&]() { // the held hit joins the lane's hits
+                    bool robust;
+                    const float term = pt_light_pdf_hit(S, S.lights_walk + h_i, o, d, h_t, h_u, h_v, h_in, robust);
                     if (COUNT && term != 0.f) prof.light_hits++;
-                    if (term != 0.f) { // a hit (a miss contributes exactly 0, and adding 0 changes nothing)
+                    if (term != 0.f) { // (a hit whose term is exactly 0 adds nothing, like a miss)
                         if (!robust || k >= WF_MAX_LIGHT_HITS || sp + 2 * k + 2 >= P8_STACK) overflow = true;
                         else { // kept sorted by light index (this tree's leaf order is not the light order): hit j at words P8_STACK-1-2j (index), -2-2j (term)
                             int j = k;
-                            while (j > 0 && stack[P8_STACK - 1 - 2 * (j - 1)][lane] > li) {
+                            while (j > 0 && stack[P8_STACK - 1 - 2 * (j - 1)][lane] > h_li) {
                                 stack[P8_STACK - 1 - 2 * j][lane] = stack[P8_STACK - 1 - 2 * (j - 1)][lane];
                                 stack[P8_STACK - 2 - 2 * j][lane] = stack[P8_STACK - 2 - 2 * (j - 1)][lane];
                                 j--;
                             }
-                            stack[P8_STACK - 1 - 2 * j][lane] = li; stack[P8_STACK - 2 - 2 * j][lane] = __float_as_uint(term); k++;
+                            stack[P8_STACK - 1 - 2 * j][lane] = h_li; stack[P8_STACK - 2 - 2 * j][lane] = __float_as_uint(term); k++;
                         }
+                    }
+                    held = false;
+                };
+                for (;;) {
+                    bool last, inside; uint32_t li; float t, u, v;
+                    if (COUNT) { n_tris++; prof.light_tests++; }
+                    steps += PT_COST_LIGHT_TEST;
+                    if (pt_light_test(S.lights_walk + i, o, d, last, li, t, u, v, inside)) {
+                        if (held) take(); // a second hit in this phase
+                        held = true; h_i = i; h_li = li; h_t = t; h_u = u; h_v = v; h_in = inside;
                     }
                     if (!last) i++;
                     else if (more == RT_EMPTY_LEAF) break;
                     else { i = more & ~RT_LEAF_BIT; more = more2; more2 = RT_EMPTY_LEAF; } // the lane's next leaf
                 }
+                if (held) take();
             }
 #if PT_POSTPONE
             pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;

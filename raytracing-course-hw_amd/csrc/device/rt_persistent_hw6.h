@@ -495,37 +495,47 @@ RT_DEV void p6_light_stint(const SceneView6 &S, const W6View &W, P6Shared &sh, c
         if (active && pend != RT_EMPTY_LEAF) { // phase 2: leaves
             {
                 uint32_t i = pend & ~RT_LEAF_BIT, more = pend2;
+                // the loop only tests; a hit's pdf term, robustness test and bookkeeping wait until after it (rt_persistent.h, pt_light_stint)
+                bool held = false; uint32_t h_i = 0u; float h_t = 0.f; bool h_in = false;
+                auto take = [&]() {
+                    const Tri6Regs T = load_tri6(S.fast_lights + h_i);
+                    const float t = h_t; const bool inside = h_in;
+                    F3 yn = normalize(inside ? neg(T.n) : T.n);                          // primitives.cpp:31
+                    F3 y = o + t * d;
+                    const float term = T.point_prob * len2(o - y) / fabsf(dot(d, yn));    // distributions.h:116-118
+                    if (S.exact_boxes) { // is every box of the reference's light tree above this hit passed whatever the rounding? (rt_exact.h)
+                        const F3 pb = T.a + T.b, pc = T.a + T.c;
+                        const F3 blo = f3(fminf(T.a.x, fminf(pb.x, pc.x)), fminf(T.a.y, fminf(pb.y, pc.y)), fminf(T.a.z, fminf(pb.z, pc.z)));
+                        const F3 bhi = f3(fmaxf(T.a.x, fmaxf(pb.x, pc.x)), fmaxf(T.a.y, fmaxf(pb.y, pc.y)), fmaxf(T.a.z, fmaxf(pb.z, pc.z)));
+                        if (!pt_box_robust<P6_LIGHT_PRETEST>(blo, bhi, y, d, t, S.box_c2)) fragile = true;
+                    }
+                    if (k == 0) { term0 = term; idx0 = T.ref_index; }
+                    else if (k == 1) { term1 = term; idx1 = T.ref_index; }
+                    else if (k == 2) { term2 = term; idx2 = T.ref_index; }
+                    else if (k == 3) { term3 = term; idx3 = T.ref_index; }
+                    else { // five or more: the hits go to the record for the slow role
+                        float2 *h = reinterpret_cast<float2 *>(p6_rec(W, slot) + 48);
+                        if (k == 4) { h[0] = make_float2(__uint_as_float(idx0), term0); h[1] = make_float2(__uint_as_float(idx1), term1); h[2] = make_float2(__uint_as_float(idx2), term2); h[3] = make_float2(__uint_as_float(idx3), term3); }
+                        if (k < RT6_MAX_LIGHT_HITS) h[k] = make_float2(__uint_as_float(T.ref_index), term);
+                        many = true;
+                    }
+                    k++;
+                    held = false;
+                };
                 for (;;) {
                     Tri6Regs T = load_tri6(S.fast_lights + i);
                     if (COUNT) n_tris++;
                     steps++;
                     float t; bool inside;
                     if (tri6_test(T, o, d, t, inside)) {
-                        F3 yn = normalize(inside ? neg(T.n) : T.n);                          // primitives.cpp:31
-                        F3 y = o + t * d;
-                        const float term = T.point_prob * len2(o - y) / fabsf(dot(d, yn));    // distributions.h:116-118
-                        if (S.exact_boxes) { // is every box of the reference's light tree above this hit passed whatever the rounding? (rt_exact.h)
-                            const F3 pb = T.a + T.b, pc = T.a + T.c;
-                            const F3 blo = f3(fminf(T.a.x, fminf(pb.x, pc.x)), fminf(T.a.y, fminf(pb.y, pc.y)), fminf(T.a.z, fminf(pb.z, pc.z)));
-                            const F3 bhi = f3(fmaxf(T.a.x, fmaxf(pb.x, pc.x)), fmaxf(T.a.y, fmaxf(pb.y, pc.y)), fmaxf(T.a.z, fmaxf(pb.z, pc.z)));
-                            if (!pt_box_robust<P6_LIGHT_PRETEST>(blo, bhi, y, d, t, S.box_c2)) fragile = true;
-                        }
-                        if (k == 0) { term0 = term; idx0 = T.ref_index; }
-                        else if (k == 1) { term1 = term; idx1 = T.ref_index; }
-                        else if (k == 2) { term2 = term; idx2 = T.ref_index; }
-                        else if (k == 3) { term3 = term; idx3 = T.ref_index; }
-                        else { // five or more: the hits go to the record for the slow role
-                            float2 *h = reinterpret_cast<float2 *>(p6_rec(W, slot) + 48);
-                            if (k == 4) { h[0] = make_float2(__uint_as_float(idx0), term0); h[1] = make_float2(__uint_as_float(idx1), term1); h[2] = make_float2(__uint_as_float(idx2), term2); h[3] = make_float2(__uint_as_float(idx3), term3); }
-                            if (k < RT6_MAX_LIGHT_HITS) h[k] = make_float2(__uint_as_float(T.ref_index), term);
-                            many = true;
-                        }
-                        k++;
+                        if (held) take(); // another hit in this phase
+                        held = true; h_i = i; h_t = t; h_in = inside;
                     }
                     if (!T.last) i++;
                     else if (more == RT_EMPTY_LEAF) break;
                     else { i = more & ~RT_LEAF_BIT; more = RT_EMPTY_LEAF; } // the lane's second leaf
                 }
+                if (held) take();
             }
             pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF;
             if (cur == PT_DRAINED || k > RT6_MAX_LIGHT_HITS) finish();

@@ -358,7 +358,7 @@ template <bool COUNT>
 RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
-    bool active = false, refill_ok = true;
+    bool active = false, refill_ok = true, ending = false; // ending: the walk is over, its record is written at the next hand-off test
     uint32_t l = 0, slot = 0, cur = 0, hit = WF_MISS, fin = PT_NONE;
     int sp = 0;
     uint32_t pend = RT_EMPTY_LEAF, pend2 = RT_EMPTY_LEAF, pend3 = RT_EMPTY_LEAF; (void)pend; (void)pend2; (void)pend3; // PT_POSTPONE: the leaves this lane has met and not yet tested (pend first)
@@ -375,6 +375,11 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     };
     PtLap<COUNT> clk;
     for (;;) {
+        // Walks that ended since the last pass write their records here, together: in the loops below a lane only marks itself, so the
+        // code of an ending (gap code, record store, cost counter) runs once per pass and not in every step in which some lane ends.
+        if (pt_ballot(ending)) {
+            if (ending) { store_hit(); fin = l; ending = false; }
+        }
         const unsigned long long idle = pt_ballot(!active);
         if (idle && (__popcll(idle) >= (P.refill & 0xFFFF) || idle == ~0ull)) {
             // Hand-off point.  Finished lanes are published here and not the moment they finish: the release (a wait for the
@@ -419,7 +424,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (active && (cur & RT_LEAF_BIT) && PT_LAST_SLOT == RT_EMPTY_LEAF && cur != PT_DRAINED) {
                 if (pend == RT_EMPTY_LEAF) pend = cur; else if (pend2 == RT_EMPTY_LEAF) pend2 = cur; else pend3 = cur; // (an empty leaf leaves the slot as it was)
                 cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
-                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) { store_hit(); active = false; fin = l; } // an empty leaf was all that was left
+                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) { active = false; ending = true; } // an empty leaf was all that was left
             }
 #endif
             const bool inner = active && !(cur & RT_LEAF_BIT);
@@ -434,9 +439,9 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #if PT_POSTPONE
                     if (sp != 0) cur = stack[--sp][lane];
                     else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
-                    else { store_hit(); active = false; fin = l; }
+                    else { active = false; ending = true; }
 #else
-                    if (sp == 0) { store_hit(); active = false; fin = l; }
+                    if (sp == 0) { active = false; ending = true; }
                     else cur = stack[--sp][lane];
 #endif
                 } else if (went == PT_WIDE_FULL) {
@@ -444,7 +449,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     // ray that grazes many boxes: triangle soups).  The walk ends here and says so — no hit has a negative t — and the
                     // exact role walks the query with a stack of its own (pt_exact_batch).
                     best_t = PT_T_OVERFLOW; best_u = 0.f; best_v = 0.f; hit = 0u; t2 = PT_T_OVERFLOW;
-                    store_hit(); active = false; fin = l; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;
+                    active = false; ending = true; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;
                 }
 #else
                 float n0, n1;
@@ -501,7 +506,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             }
 #if PT_POSTPONE
             pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;
-            if (cur == PT_DRAINED) { store_hit(); active = false; fin = l; } // a lane that stopped at a second leaf keeps that for the next round
+            if (cur == PT_DRAINED) { active = false; ending = true; } // a lane that stopped at a second leaf keeps that for the next round
 #else
             if (sp == 0) {
                 store_hit();
@@ -518,7 +523,7 @@ template <bool COUNT>
 RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, const PtParams &P, PtWave &wv, uint32_t (*stack)[64],
                            const int shade_thr, uint32_t &n_queries, unsigned long long &n_nodes, unsigned long long &n_tris, PtProf &prof) {
     const int lane = threadIdx.x & 63;
-    bool active = false, overflow = false, refill_ok = true;
+    bool active = false, overflow = false, refill_ok = true, ending = false; // ending: see pt_trace_stint
     uint32_t l = 0, slot = 0, cur = 0, fin = PT_NONE; // fin: the lane's finished, unpublished path; bit 31 = it needs the exact role instead
     int sp = 0, k = 0;
     uint32_t pend = RT_EMPTY_LEAF, pend2 = RT_EMPTY_LEAF, pend3 = RT_EMPTY_LEAF; (void)pend; (void)pend2; (void)pend3; // PT_POSTPONE: the leaves this lane has met and not yet tested (pend first)
@@ -561,6 +566,9 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
     };
     PtLap<COUNT> clk;
     for (;;) {
+        if (pt_ballot(ending)) { // the sums of the walks that ended since the last pass (pt_trace_stint)
+            if (ending) { finish(); ending = false; }
+        }
         const unsigned long long idle = pt_ballot(!active);
         if (idle && (__popcll(idle) >= (P.refill >> 16) || idle == ~0ull)) {
             if (pt_ballot(fin != PT_NONE)) { // hand-off point, see pt_trace_stint
@@ -596,7 +604,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             if (active && (cur & RT_LEAF_BIT) && PT_LAST_SLOT == RT_EMPTY_LEAF && cur != PT_DRAINED) { // the leaf waits for the next leaf phase (pt_trace_stint)
                 if (pend == RT_EMPTY_LEAF) pend = cur; else if (pend2 == RT_EMPTY_LEAF) pend2 = cur; else pend3 = cur;
                 cur = sp == 0 ? PT_DRAINED : stack[--sp][lane];
-                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) finish();
+                if (cur == PT_DRAINED && pend == RT_EMPTY_LEAF) { active = false; ending = true; }
             }
 #endif
             const bool inner = active && !(cur & RT_LEAF_BIT);
@@ -611,12 +619,12 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
 #if PT_POSTPONE
                     if (sp != 0) cur = stack[--sp][lane];
                     else if (pend != RT_EMPTY_LEAF) cur = PT_DRAINED;
-                    else finish();
+                    else { active = false; ending = true; }
 #else
-                    if (sp == 0) finish();
+                    if (sp == 0) { active = false; ending = true; }
                     else cur = stack[--sp][lane];
 #endif
-                } else if (went == PT_WIDE_FULL) { overflow = true; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF; finish(); } // no room beside the hits: the slow role sums this query
+                } else if (went == PT_WIDE_FULL) { overflow = true; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF; { active = false; ending = true; } } // no room beside the hits: the slow role sums this query
 #else
                 float n0, n1;
                 const float4 *q = reinterpret_cast<const float4 *>(S.light_walk_nodes + cur);
@@ -627,7 +635,7 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                 if (h0 & h1) { stack[sp++][lane] = c1; cur = c0; if (sp + 2 * k >= P8_STACK) overflow = true; }
                 else if (h0) cur = c0;
                 else if (h1) cur = c1;
-                else if (sp == 0) finish();
+                else if (sp == 0) { active = false; ending = true; }
                 else cur = stack[--sp][lane];
 #endif
             }
@@ -684,9 +692,9 @@ RT_DEV void pt_light_stint(const SceneView &S, const WfView &W, PtShared &sh, co
             }
 #if PT_POSTPONE
             pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF;
-            if (cur == PT_DRAINED) finish();
+            if (cur == PT_DRAINED) { active = false; ending = true; }
 #else
-            if (sp == 0) finish();
+            if (sp == 0) { active = false; ending = true; }
             else cur = stack[--sp][lane];
 #endif
         }

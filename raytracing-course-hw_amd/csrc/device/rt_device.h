@@ -221,7 +221,7 @@ typedef float rt_f2 __attribute__((ext_vector_type(2)));
 //     o' = (o - grid.lo) / step,   1/d' = step / d      (t keeps its meaning: x = o + t d  <=>  x' = o' + t d'),
 // and a child's slabs are (cell - o') * (1/d'): cells are small integers, exact in a float.  What rounds: o' — three roundings, at most
 // 3 * 2^-24 * 65,536 = 0.012 cells for an origin inside the grid (the grid covers the scene's boxes and the camera, so every ray origin)
-// — and relative errors of the subtraction, of 1/d' (two roundings beside the reciprocal's) and of the product, 5 * 2^-24 of a
+// — and relative errors of the subtraction, of 1/d' (a product and a 1-ulp reciprocal) and of the product, 6 * 2^-24 of a
 // slab's t: since origin and box both lie on the grid, that t is at most 65,536 cells' worth along its axis, so 0.02 cells.  The extra
 // cell on either side of every box (rt_node_grid.h grid_axis_word) covers both, and the interval needs no widening of its own.
 // sx, sy, sz: byte selectors (v_perm_b32) that put the slab the ray meets first into the low half of a record's axis word — lo | hi << 16
@@ -234,10 +234,12 @@ RT_DEV RayGrid ray_grid_idle() { // what an idle lane holds (never used); field 
 }
 #define RT_GRID_RAY_IDLE ray_grid_idle()
 RT_DEV RayGrid make_ray_grid(const NodeGrid &G, F3 o, F3 d) {
-    const RayInv r = make_ray_inv(o, d);
+    // reciprocals by v_rcp_f32 (1 ulp): part of the relative error the boxes' extra cell covers (below); a zero (or denormal) component is
+    // replaced as in make_ray_inv
+    const float dx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x), dy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y), dz = fabsf(d.z) > 1e-30f ? d.z : copysignf(1e-30f, d.z);
     RayGrid g;
     g.ox = (o.x - G.lo[0]) * G.istep[0]; g.oy = (o.y - G.lo[1]) * G.istep[1]; g.oz = (o.z - G.lo[2]) * G.istep[2];
-    g.ix = G.step[0] * r.inv.x; g.iy = G.step[1] * r.inv.y; g.iz = G.step[2] * r.inv.z;
+    g.ix = G.step[0] * __builtin_amdgcn_rcpf(dx); g.iy = G.step[1] * __builtin_amdgcn_rcpf(dy); g.iz = G.step[2] * __builtin_amdgcn_rcpf(dz);
     g.sx = g.ix < 0.f ? 0x01000302u : 0x03020100u; g.sy = g.iy < 0.f ? 0x01000302u : 0x03020100u; g.sz = g.iz < 0.f ? 0x01000302u : 0x03020100u;
     return g;
 }

@@ -767,10 +767,12 @@ static void redeal_groups(rt_scene *scene, const uint32_t *d_cost, uint32_t *d_o
         // The workgroups are dispatched in index order, one round of n_cus after the other, so the age rank of a workgroup on its CU is
         // its index / n_cus.  The measured slowness is split into the mean of the workgroup's round (the age effect: over-relaxed,
         // because a slow workgroup ran its last stretch with its faster neighbours already gone, so the phase shows less of a
-        // difference than an even finish will: 1.5 measured best on the 1080p frame) and the
-        // workgroup's own deviation from it (half of which is gone in the next phase: damped).
-        const double gamma_round = getenv("RTAMD_PT_SPEED_GAMMA") ? atof(getenv("RTAMD_PT_SPEED_GAMMA")) : 1.5;
-        const double gamma_own = getenv("RTAMD_PT_SPEED_GAMMA_OWN") ? atof(getenv("RTAMD_PT_SPEED_GAMMA_OWN")) : 0.4;
+        // difference than an even finish will: 2.0 measured best for the hw8 kernel on the 1080p frame — its youngest workgroups
+        // still left last at 1.5 (exit times by dispatch round 1,028 / 1,024 / 1,035 / 1,071 / 1,118 ms) — and 1.5 for the hw6 kernel) and the
+        // workgroup's own deviation from it (most of which is gone in the next phase: damped).
+        const bool hw6_kernel = scene->flavor == RT_INTEGRATOR_HW6;
+        const double gamma_round = getenv("RTAMD_PT_SPEED_GAMMA") ? atof(getenv("RTAMD_PT_SPEED_GAMMA")) : (hw6_kernel ? 1.5 : 2.0);
+        const double gamma_own = getenv("RTAMD_PT_SPEED_GAMMA_OWN") ? atof(getenv("RTAMD_PT_SPEED_GAMMA_OWN")) : (hw6_kernel ? 0.4 : 0.3);
         const uint32_t round_size = scene->n_cus > 0 && blocks % (uint32_t)scene->n_cus == 0 ? (uint32_t)scene->n_cus : blocks;
         for (uint32_t r0 = 0; r0 < blocks; r0 += round_size) {
             double lsum = 0; uint32_t ln = 0;

@@ -389,11 +389,14 @@ RT_DEV float light_pdf_sum(const SceneView &S, F3 x, F3 d, uint32_t *stack, Coun
 }
 
 // ---- textures (scene.cpp:9-53) --------------------------------------------------------------------
+// Texels are RGB8; one (unaligned) 4-byte load fetches all three channels — the texel array ends with four spare bytes (scene_prep.cpp).
+// 32-bit offsets: an image has fewer than 2^32 / 3 texels (checked at scene preparation).
 RT_DEV F3 load_texel(const SceneView &S, const GpuImage &im, int ix, int iy, bool srgb) {
-    size_t off = 3 * ((size_t)ix + (size_t)im.width * (size_t)iy);
-    if (off + 2 >= (size_t)im.width * im.height * 3) return f3(0.f, 0.f, 0.f); // reference reads OOB here (UB)
-    const uint8_t *p = S.texels + im.offset + off;
-    uint32_t r = p[0], g = p[1], b = p[2];
+    const uint32_t off = 3u * ((uint32_t)ix + (uint32_t)im.width * (uint32_t)iy);
+    if (off + 2u >= (uint32_t)im.width * (uint32_t)im.height * 3u) return f3(0.f, 0.f, 0.f); // reference reads OOB here (UB)
+    uint32_t w;
+    __builtin_memcpy(&w, S.texels + im.offset + off, 4);
+    const uint32_t r = w & 255u, g = (w >> 8) & 255u, b = (w >> 16) & 255u;
     if (srgb) return f3(S.srgb_lut[r], S.srgb_lut[g], S.srgb_lut[b]);
     const float k = (float)(1. / 255);
     return f3(k * (1.f * (float)r), k * (1.f * (float)g), k * (1.f * (float)b));
@@ -405,8 +408,9 @@ RT_DEV F3 sample_texture(const SceneView &S, GpuImage im, float tx, float ty, bo
     ty -= floorf(ty);
     tx *= im.width;
     ty *= im.height;
-    int ix1 = (int)floorf(tx), ix2 = (ix1 + 1) % im.width;
-    int iy1 = (int)floorf(ty), iy2 = (iy1 + 1) % im.height;
+    // (i + 1) % size without the integer division: i lies in [0, size] (size itself when the product rounds up), so one subtraction wraps it
+    int ix1 = (int)floorf(tx), ix2 = ix1 + 1; if (ix2 >= im.width) ix2 -= im.width;
+    int iy1 = (int)floorf(ty), iy2 = iy1 + 1; if (iy2 >= im.height) iy2 -= im.height;
     float dx = tx - ix1;
     float dy = ty - iy1;
     F3 p11 = load_texel(S, im, ix1, iy1, srgb);
@@ -601,13 +605,26 @@ RT_DEV uint8_t tonemap1(float x) {
 }
 
 // Pixel slot -> pixel: slots run through the 8x8 sub-tiles of this shard's tiles (slot >> 6 = sub-tile, slot & 63 = pixel in it).
+// n / d and n % d for n < 2^24 (exact as a float) and a wave-uniform d: a multiplication by the reciprocal and one correction step instead of
+// the ~30 instructions of a 32-bit integer division.
+RT_DEV uint32_t udiv24(uint32_t n, uint32_t d, float rcp_d, uint32_t &rem) {
+    uint32_t q = (uint32_t)((float)n * rcp_d);
+    int r = (int)(n - q * d);
+    if (r < 0) { q--; r += (int)d; } else if (r >= (int)d) { q++; r -= (int)d; }
+    rem = (uint32_t)r;
+    return q;
+}
 RT_DEV void slot_to_pixel(const RenderView &R, uint32_t slot, int &x, int &y, bool &inside, size_t &out_index) {
     const int sub_x = R.tile_w >> 3, sub_per_tile = sub_x * (R.tile_h >> 3);
-    uint32_t w = slot >> 6, lane = slot & 63u;
-    uint32_t st = w / sub_per_tile, sub = w % sub_per_tile;
+    uint32_t w = slot >> 6, lane = slot & 63u; // w < 2^24: a launch holds fewer than 2^30 slots
+    uint32_t sub, st = udiv24(w, (uint32_t)sub_per_tile, __builtin_amdgcn_rcpf((float)sub_per_tile), sub);
     uint32_t gt = R.shard_count > 1 ? (uint32_t)R.shard_index + st * (uint32_t)R.shard_count : st;
-    int tx0 = (int)(gt % (uint32_t)R.tiles_x) * R.tile_w, ty0 = (int)(gt / (uint32_t)R.tiles_x) * R.tile_h;
-    int lx = (int)(sub % sub_x) * 8 + (int)(lane & 7), ly = (int)(sub / sub_x) * 8 + (int)(lane >> 3);
+    uint32_t gtx, gty, sx, sy;
+    if (gt < (1u << 24)) gty = udiv24(gt, (uint32_t)R.tiles_x, __builtin_amdgcn_rcpf((float)R.tiles_x), gtx);
+    else { gty = gt / (uint32_t)R.tiles_x; gtx = gt % (uint32_t)R.tiles_x; }
+    sy = udiv24(sub, (uint32_t)sub_x, __builtin_amdgcn_rcpf((float)sub_x), sx);
+    int tx0 = (int)gtx * R.tile_w, ty0 = (int)gty * R.tile_h;
+    int lx = (int)sx * 8 + (int)(lane & 7), ly = (int)sy * 8 + (int)(lane >> 3);
     x = tx0 + lx; y = ty0 + ly;
     inside = x < R.width && y < R.height;
     out_index = R.shard_count > 1 ? ((size_t)st * R.tile_h + ly) * R.tile_w + lx : (size_t)y * R.width + x;

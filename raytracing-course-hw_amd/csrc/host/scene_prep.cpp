@@ -440,7 +440,9 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
         g.offset = out.texels.size();
         g.width = im.width; g.height = im.height;
         size_t bytes = (size_t)im.width * im.height * 3;
+        if (bytes >= 0xFFFFFFF0ull) throw std::runtime_error("image too large (the kernels address its texels with 32 bits)");
         out.texels.insert(out.texels.end(), im.rgb, im.rgb + bytes);
+        out.texels.push_back(0); // a texel is fetched with one 4-byte load (rt_device.h load_texel): one spare byte behind the last one
         while (out.texels.size() % 16) out.texels.push_back(0);
         out.images.push_back(g);
         return (int32_t)out.images.size() - 1;

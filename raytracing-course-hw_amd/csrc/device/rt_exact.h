@@ -208,6 +208,40 @@ RT_DEV bool pt_hit_stands(F3 lo, F3 hi, F3 o, F3 d, float t, float gap, float c2
     return worst >= need && exit_ >= need && gap > window && gap > 4.8e-7f * (t + gap) && window <= seen; // NaN compares false: exact walk
 }
 
+// Does the ray pierce one of the scene's tripwires (host/scene_prep.h: the leaf boxes of the triangles whose test accepts points far from the
+// triangle) and pass that triangle's test?  Such a ray's closest hit goes straight to the exact walk.  Conservative: the boxes carry a generous pad, the reciprocals are
+// v_rcp_f32, the interval is widened like slab_test's.  Two levels: up to four groups (wave-uniform records: scalar loads), members on a hit.
+RT_DEV bool pt_tripwire(const SceneView &S, F3 o, F3 d) {
+    if (S.n_tripwire_groups == 0u) return false;
+    const float dx = fabsf(d.x) > 1e-30f ? d.x : copysignf(1e-30f, d.x), dy = fabsf(d.y) > 1e-30f ? d.y : copysignf(1e-30f, d.y), dz = fabsf(d.z) > 1e-30f ? d.z : copysignf(1e-30f, d.z);
+    RayInv r; r.o = o; r.inv = f3(pt_rcp(dx), pt_rcp(dy), pt_rcp(dz));
+    const float4 *rec = reinterpret_cast<const float4 *>(S.tripwires);
+    bool pierced = false;
+    for (uint32_t g = 0; g < S.n_tripwire_groups; g++) {
+        const float4 lo = rec[2 * g], hi = rec[2 * g + 1];
+        float tn;
+        if (slab_test(lo, hi, r, RT_T_MAX, tn)) {
+            const uint32_t first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
+            for (uint32_t m = first; m < first + count; m++) {
+                const float4 mlo = rec[2 * m];
+                if (slab_test(mlo, rec[2 * m + 1], r, RT_T_MAX, tn)) {
+                    // The reference tests this triangle if its walk gets to the leaf; only a test that passes can change its answer, and a
+                    // hit that lies well inside the triangle's own box is an ordinary one (the walkers meet it, the gate judges it).
+                    const uint32_t fi = __float_as_uint(mlo.w);
+                    const TriIsect T = load_isect(S.tri_isect + fi);
+                    float t, u, v; bool inside;
+                    if (tri_test(T, o, d, t, u, v, inside)) {
+                        const float4 *bx = reinterpret_cast<const float4 *>(S.tri_box) + 2 * (size_t)fi;
+                        const float4 blo = bx[0], bhi = bx[1];
+                        if (!pt_deep_inside(f3(blo.x, blo.y, blo.z), f3(bhi.x, bhi.y, bhi.z), o + t * d, d, t, S.box_c2)) pierced = true;
+                    }
+                }
+            }
+        }
+    }
+    return pierced;
+}
+
 // light_pdf_one (rt_device.h) that also says whether the hit is robust against the reference's box tests (pt_box_robust on
 // the light triangle's own box: a, a + b, a + c).
 // `index`: the light's position in the reference's light order — carried by the record itself (pad >> 1) in the persistent kernel's own light

@@ -410,7 +410,7 @@ RT_DEV void pt_trace_stint(const SceneView &S, const WfView &W, PtShared &sh, co
                     cur = 0; sp = 0; pend = RT_EMPTY_LEAF; pend2 = RT_EMPTY_LEAF; pend3 = RT_EMPTY_LEAF; hit = WF_MISS; best_t = RT_T_MAX; cull_t = RT_T_MAX; t2 = 2.f * RT_T_MAX; best_u = 0.f; best_v = 0.f;
                     active = true;
                 }
-                if (COUNT) { asm volatile("" : "+v"(ray.ix)); sub.lap(prof.t_sub[0][2]); }
+                if (COUNT) { asm volatile("" : "+v"(cull_t)); sub.lap(prof.t_sub[0][2]); }
             }
         }
         const unsigned long long m_active = pt_ballot(active);
@@ -908,7 +908,15 @@ RT_DEV void pt_exact_batch(const SceneView &S, const WfView &W, SH &sh, PtWave &
     }
     n_xtrace += __popcll(pt_ballot(got != PT_NONE));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    pt_push(sh, PT_Q_SHADE, got, got != PT_NONE);
+    // A hit the gate sent here has both walks behind it: it goes back to the shaders.  A ray that came here instead of to the walkers (a
+    // tripwire, pt_tripwire) still has its closest-hit bit pending, and its light sum may be under way: the last of the two hands it on.
+    bool ready = false;
+    if (got != PT_NONE) {
+        const uint32_t shift = (got & 15u) * 2u;
+        const uint32_t old = (atomicAnd(&sh.pending[got >> 4], ~(PT_BIT_T << shift)) >> shift) & 3u;
+        ready = old == 0u || old == PT_BIT_T;
+    }
+    pt_push(sh, PT_Q_SHADE, got, ready);
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
@@ -971,7 +979,14 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
         }
         const unsigned long long m = pt_ballot(started);
         if (m && lane == 0) atomicAdd(&sh.cnt[PT_N_LIVE], (int)__popcll(m));
-        pt_push(sh, PT_Q_TRACE, l, started);
+        bool wire = false;
+        if (S.n_tripwire_groups && started) {
+            const float4 *nr = wf_rec(W, pt_slot(sh, l));
+            const float4 n0 = nr[0], n1 = nr[1];
+            wire = pt_tripwire(S, f3(n0.x, n0.y, n0.z), f3(n0.w, n1.x, n1.y));
+        }
+        pt_push(sh, PT_Q_TRACE, l, started && !wire);
+        pt_push(sh, PT_Q_XTRACE, l, wire);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
@@ -1022,11 +1037,17 @@ __global__ __launch_bounds__(P8_THREADS, P8_PER_CU) void pt_persistent_kernel(Sc
 #endif
             n_discarded += __popcll(pt_ballot(discarded));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            const bool next = got != PT_NONE && (todo & WF_NEXT_TRACE), with_light = next && (todo & WF_NEXT_LIGHT);
+            const bool next = got != PT_NONE && todo != PT_SHADE_EXACT && (todo & WF_NEXT_TRACE), with_light = next && (todo & WF_NEXT_LIGHT);
+            bool wire = false; // the new ray pierces a tripwire (rt_exact.h): its closest hit is the exact role's
+            if (S.n_tripwire_groups && next) {
+                const float4 *nr = wf_rec(W, pt_slot(sh, got));
+                const float4 n0 = nr[0], n1 = nr[1];
+                wire = pt_tripwire(S, f3(n0.x, n0.y, n0.z), f3(n0.w, n1.x, n1.y));
+            }
             if (next) atomicOr(&sh.pending[got >> 4], (PT_BIT_T | (with_light ? PT_BIT_L : 0u)) << ((got & 15u) * 2u));
-            pt_push(sh, PT_Q_TRACE, got, next);
+            pt_push(sh, PT_Q_TRACE, got, next && !wire);
             pt_push(sh, PT_Q_LIGHT, got, with_light);
-            pt_push(sh, PT_Q_XTRACE, got, got != PT_NONE && todo == PT_SHADE_EXACT);
+            pt_push(sh, PT_Q_XTRACE, got, (got != PT_NONE && todo == PT_SHADE_EXACT) || wire);
             if (got != PT_NONE && todo != PT_SHADE_EXACT) atomicAdd(&sh.cost[got >> pt_gshift(sh)], (uint32_t)PT_COST_SHADE);
             const unsigned long long done = pt_ballot(got != PT_NONE && (todo == 0 || todo == WF_PARKED)); // finished, or parked for the next phase
             if (done && lane == 0) atomicSub(&sh.cnt[PT_N_LIVE], (int)__popcll(done));

@@ -101,6 +101,8 @@ struct SceneView {
     // records in ITS leaf order, pad = light index (position in `lights`) << 1 | last-of-leaf.  == light_nodes / lights with pads rewritten when the
     // scene has too few lights to bother (then the index is the position).
     const GpuNode *light_walk_nodes;
+    const float *tripwires;        // host/scene_prep.h: boxes a ray must not pierce unnoticed (8 floats per record: groups, then members); rt_exact.h pt_tripwire
+    uint32_t n_tripwire_groups;
     const GpuNode4Q *nodes4, *light_walk_nodes4;  // `nodes` / `light_walk_nodes` four wide on the 16-bit grid: what the persistent pipeline's walkers read
     NodeGrid grid;                 // covers both trees' root boxes and the camera (every ray origin lies inside it)
     const LightRec *lights_walk;

@@ -16,6 +16,7 @@
 #include "scene_prep.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <limits>
@@ -404,6 +405,76 @@ void prepare_scene(const rt_scene_desc &d, PreparedScene &out, bool tree_on_devi
     }
     out.box_c2 = max_coord * 9.5367431640625e-07f; // 2^-20
     for (uint32_t i : scene_leaf_last) out.isect[i].pad |= 1u;
+    out.tripwires.clear(); out.n_tripwire_groups = 0;
+    if (!out.walk_box.empty()) { // replay mode: the tripwires of scene_prep.h
+        // |den| / (|n| |k|) = |cos| of the angle between the triangle's normal and the projection's kernel k = magic1 x magic2: how far
+        // outside the triangle the test can still accept a point grows like (rounding of the hit point) / cos.  Below 2^-14 (20 triangles of the
+        // benchmark scene; 8 lie below 1e-5, one at 4e-8: its test accepted a point 16 units away) the walkers' look-behind and the gate's
+        // window (rt_exact.h) no longer cover it; every ray pays for the test, so the list is kept short.
+        const double m1[3] = {0.239f, 0.419f, 0.533f}, m2[3] = {0.35743f, 0.66682f, 0.69695f};
+        const double kx = m1[1] * m2[2] - m1[2] * m2[1], ky = m1[2] * m2[0] - m1[0] * m2[2], kz = m1[0] * m2[1] - m1[1] * m2[0];
+        const double kn = std::sqrt(kx * kx + ky * ky + kz * kz);
+        const double tripwire_cos = getenv("RTAMD_TRIPWIRE_COS") ? atof(getenv("RTAMD_TRIPWIRE_COS")) : 6.103515625e-05; // 2^-14
+        struct Wire { uint64_t key; float lo[3], hi[3]; uint32_t figure; };
+        std::vector<Wire> wires;
+        float slo[3] = {3e38f, 3e38f, 3e38f}, shi[3] = {-3e38f, -3e38f, -3e38f};
+        for (uint32_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) { slo[k] = smin(slo[k], out.walk_box[8 * (size_t)i + k]); shi[k] = smax(shi[k], out.walk_box[8 * (size_t)i + 4 + k]); }
+        for (uint32_t i = 0; i < n; i++) {
+            const TriIsect &T = out.isect[i];
+            const double nn = std::sqrt((double)T.nx * T.nx + (double)T.ny * T.ny + (double)T.nz * T.nz);
+            if (!(nn > 0.0)) continue;                                       // no plane: its test never passes (t is NaN or infinite)
+            if (std::fabs((double)T.den) >= tripwire_cos * nn * kn) continue;
+            Wire w;
+            const float pad = 1e-4f * max_coord + 1e-30f;                    // far more than any rounding of the reference's box test
+            uint64_t key = 0;
+            for (int k = 0; k < 3; k++) {
+                w.lo[k] = out.walk_box[8 * (size_t)i + k] - pad; w.hi[k] = out.walk_box[8 * (size_t)i + 4 + k] + pad;
+                const double c = 0.5 * ((double)w.lo[k] + w.hi[k]), e = (double)shi[k] - slo[k];
+                const uint64_t q = e > 0 ? (uint64_t)std::fmin(1023.0, std::fmax(0.0, (c - slo[k]) / e * 1024.0)) : 0;
+                for (int b = 0; b < 10; b++) key |= ((q >> b) & 1ull) << (3 * b + k);       // Morton code: neighbours end up in one group
+            }
+            w.key = key;
+            w.figure = i;
+            wires.push_back(w);
+        }
+        std::sort(wires.begin(), wires.end(), [](const Wire &a, const Wire &b) { return a.key < b.key; });
+        // Groups: the wires lie in a few far-apart families (the band of a sphere's triangles whose normals are perpendicular to k), and a group's
+        // box must stay small — a ray that pierces it pays for its members.  Neighbouring runs of the Morton order are merged, cheapest union
+        // (by surface area) first, until at most four are left.
+        struct Run { size_t first, last; float lo[3], hi[3]; };
+        std::vector<Run> runs;
+        for (size_t m = 0; m < wires.size(); m++) { Run r; r.first = m; r.last = m + 1; for (int k = 0; k < 3; k++) { r.lo[k] = wires[m].lo[k]; r.hi[k] = wires[m].hi[k]; } runs.push_back(r); }
+        auto area_of_union = [](const Run &a, const Run &b) {
+            double e[3];
+            for (int k = 0; k < 3; k++) e[k] = (double)smax(a.hi[k], b.hi[k]) - (double)smin(a.lo[k], b.lo[k]);
+            return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+        };
+        while (runs.size() > 4) {
+            size_t best = 0; double best_area = 1e300;
+            for (size_t j = 0; j + 1 < runs.size(); j++) { const double ar = area_of_union(runs[j], runs[j + 1]); if (ar < best_area) { best_area = ar; best = j; } }
+            Run &a = runs[best]; const Run &b2 = runs[best + 1];
+            a.last = b2.last;
+            for (int k = 0; k < 3; k++) { a.lo[k] = smin(a.lo[k], b2.lo[k]); a.hi[k] = smax(a.hi[k], b2.hi[k]); }
+            runs.erase(runs.begin() + (long)best + 1);
+        }
+        const size_t n_groups = runs.size();
+        out.n_tripwire_groups = (uint32_t)n_groups;
+        if (getenv("RTAMD_DUMP_TRIPWIRES")) // diagnostic
+            for (const Run &r : runs) fprintf(stderr, "[rtamd] tripwire group: %zu wires, box %.3f %.3f %.3f .. %.3f %.3f %.3f\n", r.last - r.first, r.lo[0], r.lo[1], r.lo[2], r.hi[0], r.hi[1], r.hi[2]);
+        out.tripwires.assign((n_groups + wires.size()) * 8, 0.f);
+        for (size_t g = 0; g < n_groups; g++) {
+            const size_t first = runs[g].first, last = runs[g].last;
+            float *rec = &out.tripwires[8 * g];
+            for (int k = 0; k < 3; k++) { rec[k] = runs[g].lo[k]; rec[4 + k] = runs[g].hi[k]; }
+            for (size_t m = first; m < last; m++) {
+                float *mr = &out.tripwires[8 * (n_groups + m)];
+                for (int k = 0; k < 3; k++) { mr[k] = wires[m].lo[k]; mr[4 + k] = wires[m].hi[k]; }
+                memcpy(&mr[3], &wires[m].figure, 4);
+            }
+            const uint32_t first_rec = (uint32_t)(n_groups + first), count = (uint32_t)(last - first);
+            memcpy(&rec[3], &first_rec, 4); memcpy(&rec[7], &count, 4);
+        }
+    }
     out.lights.resize(n_lights);
     for (uint32_t i = 0; i < n_lights; i++) {
         uint32_t src = out.light_order[i];

@@ -22,6 +22,16 @@ struct PreparedScene {
     // walker uses a tree of its own over these (built on the GPU): the reference's light tree also holds the far-apart ceiling quads and
     // the lamp near its root, so its upper boxes span the room and most rays descend into them in vain.
     std::vector<float> light_walk_box;
+    // Tripwires (device/rt_exact.h pt_tripwire): the reference's triangle test solves the hit's barycentrics in a fixed projection
+    // (primitives.cpp:85-104); for a triangle whose plane (nearly) contains that projection's kernel direction the system is (nearly)
+    // singular and the test accepts points anywhere on the plane — a "hit" metres away from the triangle, which the reference finds or not
+    // depending on whether its walk enters the triangle's leaf box before a closer hit prunes it.  No culling walk can know that, so a ray
+    // that pierces the leaf box of such a triangle anywhere AND passes that triangle's test (the reference would test it if its walk got there) goes
+    // to the exact walk at once.  Layout: n_tripwire_groups records of two
+    // float4 {lo.xyz, first member | hi.xyz, member count} (indices as raw bits), then the members' boxes {lo.xyz, figure index | hi.xyz, -}; empty when
+    // the reference's tree is not replayed.
+    std::vector<float> tripwires;
+    uint32_t n_tripwire_groups = 0;
     float box_c2 = 0.f;
     float box_pad = 0.f;   // absolute part of the walkers' box padding (scene_prep.cpp pad_box): 2^-18 x the largest |coordinate|
     // Order of the light-pdf additions without walking the reference tree: light_sep[j * n_lights + i] = the shallowest

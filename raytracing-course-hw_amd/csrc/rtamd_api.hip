@@ -403,6 +403,8 @@ int rtamd::scene_create_shared(const rt_scene_desc *desc, rt_scene **out, rtamd:
         V.cull_k = getenv("RTAMD_CULL_K") ? (float)atof(getenv("RTAMD_CULL_K")) : 0.0078125f;
         V.exact_boxes = (getenv("RTAMD_NO_EXACT_BOXES") || fast_build) ? 0u : 1u; // RT_BUILD_DEVICE_BVH: there is no reference tree to be exact about
         if (getenv("RTAMD_DIAG_LOOKBEHIND_ONLY")) V.exact_boxes = 2u; // diagnostic (timing only, pixels NOT exact): the walkers look behind as with the gate, every hit stands
+        V.n_tripwire_groups = (V.exact_boxes != 1u || getenv("RTAMD_NO_TRIPWIRES")) ? 0u : P.n_tripwire_groups; // part of the exactness machinery
+        V.tripwires = V.n_tripwire_groups ? keep(upload(P.tripwires, bytes)) : nullptr;
         V.lights = keep(upload(P.lights, bytes));
         uint32_t n_light_walk_nodes = 0;
         {   // the light walker's own tree (rt_types.h: light_walk_nodes / lights_walk)

@@ -2,6 +2,7 @@
 #include "device/rt_bvh_build.h"
 #include "device/rt_node_grid.h"
 #include "host/device_build.h"
+#include "host/fold_nodes.h"
 #include "host/hip_check.h"
 #include <cmath>
 #include <stdexcept>
@@ -37,43 +38,8 @@ GpuNode4Q *widen_nodes(const GpuNode *d_nodes, uint32_t n, const NodeGrid &grid,
     std::vector<GpuNode> nodes(n ? n : 1);
     if (n) HIP_CHECK(hipMemcpy(nodes.data(), d_nodes, (size_t)n * sizeof(GpuNode), hipMemcpyDeviceToHost));
     else { GpuNode e{}; e.child0 = e.child1 = (int32_t)0xFFFFFFFFu; nodes[0] = e; }
-    struct Entry { const float *lo, *hi; uint32_t child; };
     std::vector<GpuNode4Q> wide;
-    std::vector<uint32_t> source{0u}, level{1u}; // wide node -> the two-box node it folds, its level
-    wide.reserve(nodes.size() / 2 + 1);
-    uint32_t misfits = 0;
-    depth_out = 1;
-    for (size_t w = 0; w < source.size(); w++) {
-        const GpuNode &b = nodes[source[w]];
-        Entry e[4]; int ne = 0;
-        auto take = [&](const float *lo, const float *hi, uint32_t child) {
-            if (child == 0xFFFFFFFFu) return;                       // empty
-            if (child & 0x80000000u) { e[ne++] = Entry{lo, hi, child}; return; } // leaf: stays
-            if (child >= nodes.size()) throw std::runtime_error("widen_nodes: child index out of range");
-            const GpuNode &c = nodes[child];                         // inner: its two children take its place
-            const uint32_t cc[2] = {(uint32_t)c.child0, (uint32_t)c.child1};
-            const float *clo[2] = {c.lo0, c.lo1}, *chi[2] = {c.hi0, c.hi1};
-            for (int k = 0; k < 2; k++) if (cc[k] != 0xFFFFFFFFu) e[ne++] = Entry{clo[k], chi[k], cc[k]};
-        };
-        take(b.lo0, b.hi0, (uint32_t)b.child0);
-        take(b.lo1, b.hi1, (uint32_t)b.child1);
-        GpuNode4Q q;
-        for (int k = 0; k < 4; k++) {
-            if (k >= ne) { q.rec[k][0] = q.rec[k][1] = q.rec[k][2] = 0u; q.rec[k][3] = 0xFFFFFFFFu; continue; } // a point in the grid's border
-            bool fits = true;
-            for (int a = 0; a < 3; a++) q.rec[k][a] = grid_axis_word(e[k].lo[a], e[k].hi[a], grid.lo[a], grid.step[a], fits);
-            if (!fits) misfits++;
-            uint32_t child = e[k].child;
-            if (!(child & 0x80000000u)) { // inner: gets the next wide node
-                source.push_back(child); level.push_back(level[w] + 1);
-                if (level[w] + 1 > depth_out) depth_out = level[w] + 1;
-                child = (uint32_t)(source.size() - 1);
-            }
-            q.rec[k][3] = child;
-        }
-        wide.push_back(q);
-    }
-    if (misfits) throw std::runtime_error("widen_nodes: " + std::to_string(misfits) + " node boxes do not fit the scene's grid");
+    fold_nodes(nodes, grid, wide, depth_out);
     n_out = (uint32_t)wide.size();
     GpuNode4Q *out = nullptr;
     HIP_CHECK(hipMalloc((void **)&out, wide.size() * sizeof(GpuNode4Q)));

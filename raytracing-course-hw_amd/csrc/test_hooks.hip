@@ -4,6 +4,9 @@
 #include "device/rt_device.h"
 #include "device/rt_exact.h"
 #include "device/rt_node_grid.h"
+#include "host/fold_nodes.h"
+#include <cstring>
+#include <vector>
 
 using namespace rtamd::dev;
 
@@ -55,6 +58,22 @@ __global__ void k_slab_q(const float *in, rtamd::NodeGrid G, uint32_t *out, size
 }
 
 extern "C" {
+// host/fold_nodes.h on host memory (no GPU needed): nodes = n two-box nodes of 64 bytes, grid_box = lo.xyz hi.xyz of what the grid must hold,
+// out = room for cap wide nodes of 64 bytes, grid_out = the grid's lo[3], step[3], istep[3].  Returns the number of wide nodes, -1 on error.
+int rtt_fold_nodes(const void *nodes, uint32_t n, const float *grid_box, void *out, uint32_t cap, uint32_t *depth_out, float *grid_out) {
+    try {
+        std::vector<rtamd::GpuNode> in((const rtamd::GpuNode *)nodes, (const rtamd::GpuNode *)nodes + n);
+        const rtamd::NodeGrid G = rtamd::make_node_grid(grid_box, grid_box + 3);
+        std::vector<rtamd::GpuNode4Q> wide;
+        uint32_t depth = 0;
+        rtamd::fold_nodes(in, G, wide, depth);
+        if (wide.size() > cap) return -1;
+        memcpy(out, wide.data(), wide.size() * sizeof(rtamd::GpuNode4Q));
+        *depth_out = depth;
+        for (int k = 0; k < 3; k++) { grid_out[k] = G.lo[k]; grid_out[3 + k] = G.step[k]; grid_out[6 + k] = G.istep[k]; }
+        return (int)wide.size();
+    } catch (...) { return -1; }
+}
 // grid_box: lo.xyz hi.xyz of what the grid must hold.  out bits: 1 float box entered, 2 grid box entered, 4 the box fits the grid, 8 grid entry <= float entry
 int rtt_slab_q(const float *cases, const float *grid_box, uint32_t *out, size_t n) {
     const rtamd::NodeGrid G = rtamd::make_node_grid(grid_box, grid_box + 3);

@@ -772,6 +772,10 @@ RT_DEV int pt_shade_item(const SceneView &S, const RenderView &R, const WfView &
         const float4 q2 = r[2];
         const uint32_t hit = __float_as_uint(q2.w);
         const uint32_t packed = __float_as_uint(reinterpret_cast<const float *>(r + 3)[3]);
+        if (S.n_tripwire_groups && !(packed & WF_VERIFIED_BIT)) { // the ray crossed a tripwire (rt_exact.h pt_tripwire): hit or miss, the exact walk decides
+            const float4 q0 = r[0], q1 = r[1];
+            if (pt_tripwire(S, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y))) return PT_SHADE_EXACT;
+        }
         if (hit != WF_MISS && !(packed & WF_VERIFIED_BIT)) {
             const float4 q0 = r[0], q1 = r[1];
             const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q0.w, q1.x, q1.y);

@@ -1128,12 +1128,13 @@ int rt_render(rt_scene *scene, const rt_render_params *p, float *out_rgb, uint8_
         if (scene->flavor == RT_INTEGRATOR_HW6 || txt_scene) use_wavefront = false;
         if (R.samples / streams >= (1 << 25)) use_wavefront = false; // the path record keeps the sample index in 25 bits
         // persistent dataflow pipeline (default) | round pipeline (RTAMD_KERNEL=wavefront, and for trees deeper than the LDS stack columns)
-        // The persistent pipeline is the default at every size: it takes reference-exact box decisions at no measurable cost (the exact
-        // walks hide behind the other waves of the workgroup) and keeps a small path population — a shard of a multi-GPU frame — near
-        // the full rate.  The round pipeline is ~5 % ahead on a full 1080p frame (20 traversal waves per CU against 16) but keeps the
-        // padded box test's answer: its exact re-walks would sit on the critical path of every round (a serial walk of the reference
-        // tree takes ~1.5 ms; RTAMD_ROUNDS_EXACT=1 switches them on for testing).  RTAMD_AUTO_GROUPS_PER_CU=n: opt into the round
-        // pipeline from n sub-tiles per CU on.
+        // The persistent pipeline is the default at every size: it takes reference-exact box decisions at no measurable cost for the exact
+        // walks themselves (they hide behind the other waves of the workgroup), keeps a small path population — a shard of a multi-GPU
+        // frame — near the full rate, and since round 3 (five waves per SIMD, four-wide grid nodes, postponed leaves) it is a third faster
+        // than the round pipeline on a full 1080p frame.  The round pipeline stands in for trees deeper than the LDS stack columns, then with
+        // its exact kernels on (a serial walk of the reference tree, ~1.5 ms, sits on the critical path of every round); chosen explicitly
+        // (RTAMD_KERNEL=wavefront) it keeps the padded box test's answer unless RTAMD_ROUNDS_EXACT=1.  RTAMD_AUTO_GROUPS_PER_CU=n: opt
+        // into the round pipeline from n sub-tiles per CU on.
         bool use_persistent = use_wavefront && !(ksel && strcmp(ksel, "wavefront") == 0) &&
                               scene->info.bvh_depth <= P8_STACK && scene->light_walk_depth <= P8_STACK && !getenv("RTAMD_WF_LDS_STACK");
         if (use_persistent && !ksel) {

@@ -16,6 +16,9 @@
 //   * every wave picks a role when it is idle: closest-hit walker, light-sum walker or shader, by the populations of the
 //     bitmaps; walkers keep their lanes full by refilling idle lanes from the bitmap; a shader takes up to 64 paths,
 //     finishes their pending bounce, shades the new hit and sets the bits of what each path needs next;
+//   * the walkers read four-wide nodes on a 16-bit grid (rt_types.h GpuNode4Q: two tree levels per 64-byte fetch, the ray in grid
+//     coordinates), park the leaves they meet for a common leaf phase, and leave what only a few lanes need (a light hit's pdf
+//     term, the record of a walk that has ended) for once per pass;
 //   * the speculative pairing of rt_wavefront.h is kept: a bounce's sampled direction is traced for the next hit at the
 //     same time as its light-pdf sum is walked; a 2-bit "pending" field per path joins the two (whoever finishes last sets
 //     need_shade).
@@ -30,15 +33,14 @@
 // as it stands when the hit point lies robustly inside its triangle's box (pt_box_robust: then every ancestor box passes the
 // reference's test whatever the rounding) and no second triangle was hit within a few ulp of it; the rare others are walked
 // again by the `exact` role with the reference's arithmetic on the unpadded boxes of the reference tree (ref_closest_hit,
-// ref_light_pdf_sum).  Pixels then match the reference's also where a ray grazes a box corner.
+// ref_light_pdf_sum).  Pixels then match the reference's also where a ray grazes a box corner.  Rays that cross a tripwire (rt_exact.h
+// pt_tripwire: the leaf box of a triangle whose test accepts points far away from it) never go to the walkers at all.
 #pragma once
 #include "rt_wavefront.h"
 
 namespace rtamd {
 namespace dev {
 
-#define PT_THREADS 1024               // hw6 (rt_persistent_hw6.h): one 16-wave workgroup per CU
-#define PT_WAVES 16
 // hw8 / hw7: workgroups of FOUR waves (one per SIMD), FIVE resident per CU = five waves per SIMD.  That takes <= 96 VGPRs per wave (no
 // scratch), 24-entry stack columns (4 x 24 x 256 B = 24 KB per workgroup) and 1.4 bytes of LDS per path for bitmaps and group tables: 31.7 KB per
 // workgroup, five of which fill the CU's 160 KB (handed out in 1,280-byte granules: 25 granules each).

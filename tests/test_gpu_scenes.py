@@ -225,6 +225,13 @@ def test_full_config_1920x1080x256_crops_match_oracle(rt, tmp_path):
     # Pixels found by rendering the frame on two different trees and tracing the disagreements query by query: the
     # reference prunes a box behind an earlier hit although its own triangle test reports a closer "hit" in front of that box
     # ((1918,187), (1064,478), (1356,258), (696,647)), or meets the hit in a face of its box; at 32 spp they were off by up to 6e-4.
+    # Found by a 300-tile sweep in round 3 (tests/diagnostics/validate_headline.py): at sample ~40 of pixel (1618,967) a ray crosses the leaf box
+    # of a sphere triangle whose plane contains the kernel of the reference's projection; the reference "hits" it 16 units away from the
+    # triangle, before the real hit.  Only the tripwires (rt_exact.h pt_tripwire) get this pixel right, and only at the full 256 spp.
+    for (x, y) in [(1618, 967)]:
+        x0, y0 = x - 4, y - 4
+        ref, _, _ = orc.render(1920, 1080, 256, rect=(x0, y0, 8, 8))
+        assert np.array_equal(rgb[y0:y0 + 8, x0:x0 + 8], ref), f"block at ({x0},{y0}) differs from the oracle at 256 spp (tripwires)"
     rgb32, _, st32 = scene.render(1920, 1080, 32, want_rgb8=False)
     for (x, y) in [(1918, 187), (1064, 478), (1356, 258), (696, 647), (692, 26), (1457, 113), (542, 163), (1899, 278)]:
         x0, y0 = min(max(x - 4, 0), 1912), min(max(y - 4, 0), 1072)
